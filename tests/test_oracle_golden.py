@@ -1,0 +1,62 @@
+"""The numpy oracle reproduces the reference's own outputs AND autograd gradients
+(golden vectors made by tools/gen_golden.py from the imported reference)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from oracle import edgewise, multihop, quartet, sdpa
+
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def _check(out, dx, grads, d, gref, scale=1.0):
+    np.testing.assert_allclose(out, d["y"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dx, d["dx"], **TOL)
+    assert set(grads) == set(gref)
+    for k in gref:
+        ref = gref[k]
+        tol = max(2e-5, 2e-4 * float(np.abs(ref).max()))
+        np.testing.assert_allclose(np.asarray(grads[k]).reshape(ref.shape), ref, rtol=2e-4, atol=tol, err_msg=k)
+
+
+@pytest.mark.parametrize("name", golden_names("ew_"))
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_edgewise(name, dtype):
+    d, params, gref, meta = load_golden(name)
+    if dtype == np.float32 and "_ns_" in name:
+        pytest.skip("big case checked in float64 only (speed)")
+    p = {k: v.astype(dtype) for k, v in params.items()}
+    out, cache = edgewise.module_fwd(d["x"].astype(dtype), p, meta["heads"], meta["n_views"],
+                                     bool(meta["share_qkv"]), meta["beta_not"])
+    dx, grads = edgewise.module_bwd(d["w"].astype(dtype), cache)
+    _check(out, dx, grads, d, gref)
+
+
+@pytest.mark.parametrize("name", golden_names("mh_"))
+def test_multihop(name):
+    d, params, gref, meta = load_golden(name)
+    p = {k: v.astype(np.float64) for k, v in params.items()}
+    gates = dict(and_=meta["g_and"], or_=meta["g_or"], not_=meta["g_not"], chain=meta["g_chain"])
+    out, cache = multihop.module_fwd(d["x"].astype(np.float64), p, meta["heads"], gates,
+                                     meta["beta_not"], meta["hops"], d.get("attn_mask"))
+    dx, grads = multihop.module_bwd(d["w"].astype(np.float64), cache)
+    _check(out, dx, grads, d, gref)
+
+
+@pytest.mark.parametrize("name", golden_names("qt_"))
+def test_quartet(name):
+    d, params, gref, meta = load_golden(name)
+    p = {k: v.astype(np.float64) for k, v in params.items()}
+    out, cache = quartet.module_fwd(d["x"].astype(np.float64), p, meta["heads"],
+                                    bool(meta["use_quartet"]), meta["eps"], d.get("attention_mask"))
+    dx, grads = quartet.module_bwd(d["w"].astype(np.float64), cache)
+    _check(out, dx, grads, d, gref)
+
+
+@pytest.mark.parametrize("name", golden_names("sdpa_"))
+def test_sdpa(name):
+    d, params, gref, meta = load_golden(name)
+    p = {k: v.astype(np.float64) for k, v in params.items()}
+    out, cache = sdpa.baseline_module_fwd(d["x"].astype(np.float64), p, meta["heads"], d.get("attn_mask"))
+    dx, grads = sdpa.baseline_module_bwd(d["w"].astype(np.float64), cache)
+    _check(out, dx, grads, d, gref)

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation on CPU.
+
+Run only in the build container (the reference tree is not shipped anywhere):
+
+    PYTHONDONTWRITEBYTECODE=1 MOP_REFERENCE=/root/reference python tools/gen_golden.py
+
+Imports `mop.models` from $MOP_REFERENCE, builds each module under a fixed seed,
+perturbs degenerate initialisations (identical views under
+share_qkv, zero low-rank biases, mixture=-5), runs forward and autograd backward
+of L = sum(y * w) in float32 on CPU, and writes inputs / parameters / outputs /
+gradients to tests/golden/<case>.npz.  Only data is written; no reference source.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = os.environ.get("MOP_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from mop.models.attention_variants import (BaselineMSA, EdgewiseMSA,  # noqa: E402
+                                           MultiHopMSA)
+from mop.models.quartet_attn_patch import (CausalSelfAttention,  # noqa: E402
+                                           TransformerConfig)
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _perturb(mod: torch.nn.Module, seed: int):
+    g = torch.Generator().manual_seed(seed + 1000)
+    with torch.no_grad():
+        for name, p in mod.named_parameters():
+            if name.endswith(("q_scale", "k_scale", "v_scale")):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif "row_proj.weight" in name or "col_proj.weight" in name:
+                p.mul_(3.0)
+            elif "row_proj.bias" in name or "col_proj.bias" in name:
+                p.add_(0.3 * torch.randn(p.shape, generator=g))
+            elif name.endswith("mixture"):
+                p.fill_(0.3)
+            elif name.endswith("quartet_scale"):
+                p.fill_(0.8)
+            elif name.endswith("chain_value_logit"):
+                p.fill_(-0.5)
+
+
+def _run(mod, x, fwd_kwargs=None, extra=None, hook=None):
+    fwd_kwargs = fwd_kwargs or {}
+    x = x.clone().requires_grad_(True)
+    inter = {}
+    y = mod(x, **fwd_kwargs)
+    g = torch.Generator().manual_seed(4242)
+    w = torch.randn(y.shape, generator=g)
+    (y * w).sum().backward()
+    out = {"x": x.detach().numpy(), "y": y.detach().numpy(), "w": w.numpy(),
+           "dx": x.grad.numpy()}
+    for k, v in mod.state_dict().items():
+        out["param:" + k] = v.detach().numpy()
+    for k, p in mod.named_parameters():
+        out["grad:" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy()
+    if extra:
+        out.update(extra)
+    out.update(inter)
+    return out
+
+
+def _save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez(path, **d)
+    print(f"{name:40s} {os.path.getsize(path) / 1e6:7.3f} MB  |y|max={np.abs(d['y']).max():.4f}")
+
+
+def edgewise_cases():
+    cases = [
+        # name, dim, heads, B, N, kwargs
+        ("ew_tiny_shared_v2_r2_neutral", 64, 4, 2, 8, dict(n_views=2, share_qkv=True, gate_rank=2, gate_init="neutral")),
+        ("ew_tiny_shared_v3_r4_mix5", 64, 4, 2, 8, dict(n_views=3, share_qkv=True, gate_rank=4, gate_init="mix5")),
+        ("ew_tiny_unshared_v2_r4_xor", 64, 4, 2, 8, dict(n_views=2, share_qkv=False, gate_rank=4, gate_init="xor")),
+        ("ew_tiny_unshared_v3_r2_and", 64, 4, 2, 8, dict(n_views=3, share_qkv=False, gate_rank=2, gate_init="and")),
+        ("ew_odd_shared_v5_r4_mix5", 32, 2, 1, 6, dict(n_views=5, share_qkv=True, gate_rank=4, gate_init="mix5")),
+        ("ew_mid_shared_v5_r4_chain", 128, 2, 2, 50, dict(n_views=5, share_qkv=True, gate_rank=4, gate_init="chain", beta_not=0.7)),
+        ("ew_mid_shared_v4_r3_not", 96, 3, 3, 33, dict(n_views=4, share_qkv=True, gate_rank=3, gate_init="not")),
+        ("ew_ns_shared_v5_r4_mix5", 384, 6, 1, 197, dict(n_views=5, share_qkv=True, gate_rank=4, gate_init="mix5")),
+    ]
+    for i, (name, dim, heads, B, N, kw) in enumerate(cases):
+        torch.manual_seed(100 + i)
+        mod = EdgewiseMSA(dim, heads, gate_mode="lowrank", **kw).eval()
+        _perturb(mod, 100 + i)
+        x = torch.randn(B, N, dim)
+        meta = dict(kind="edgewise", dim=dim, heads=heads, beta_not=kw.get("beta_not", 0.5),
+                    n_views=kw["n_views"], share_qkv=kw["share_qkv"], gate_rank=kw["gate_rank"])
+        extra = {"meta:" + k: np.asarray(v) for k, v in meta.items()}
+        _save(name, _run(mod, x, extra=extra))
+
+
+def multihop_cases():
+    cases = [
+        ("mh_tiny_default", 64, 4, 2, 8, dict(), False),
+        ("mh_tiny_allgates_h2", 64, 4, 2, 8, dict(gates=dict(and_=0.7, or_=0.4, not_=0.3, chain=0.5), hops=2, beta_not=0.6), False),
+        ("mh_mid_allgates_h3_causal", 96, 3, 2, 33, dict(gates=dict(and_=0.9, or_=0.5, not_=0.2, chain=0.3), hops=3), True),
+        ("mh_mid_default_causal", 128, 2, 2, 50, dict(), True),
+        ("mh_n197_default", 128, 2, 1, 197, dict(), False),
+    ]
+    for i, (name, dim, heads, B, N, kw, causal) in enumerate(cases):
+        torch.manual_seed(200 + i)
+        mod = MultiHopMSA(dim, heads, **kw).eval()
+        _perturb(mod, 200 + i)
+        x = torch.randn(B, N, dim)
+        fk, extra = {}, {}
+        if causal:
+            mask = torch.tril(torch.ones(N, N)).view(1, 1, N, N)
+            fk["attn_mask"] = mask
+            extra["attn_mask"] = mask.numpy()
+        g = kw.get("gates", dict(and_=1.0, or_=0.0, not_=0.0, chain=0.0))
+        meta = dict(kind="multihop", dim=dim, heads=heads, beta_not=kw.get("beta_not", 0.5),
+                    hops=kw.get("hops", 3), g_and=g["and_"], g_or=g["or_"], g_not=g["not_"],
+                    g_chain=g["chain"])
+        extra.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
+        _save(name, _run(mod, x, fk, extra))
+
+
+def quartet_cases():
+    cases = [
+        ("qt_tiny_quartet", 64, 4, 2, 16, True, False, False),
+        ("qt_tiny_plain", 64, 4, 2, 16, False, False, False),
+        ("qt_mid_quartet_bias_addmask", 96, 3, 2, 40, True, True, True),
+        ("qt_slice_quartet", 128, 2, 1, 256, True, False, False),
+    ]
+    for i, (name, dim, heads, B, T, uq, bias, addmask) in enumerate(cases):
+        torch.manual_seed(300 + i)
+        cfg = TransformerConfig(n_head=heads, n_embd=dim, block_size=max(T, 16), dropout=0.0,
+                                bias=bias, use_quartet=uq)
+        mod = CausalSelfAttention(cfg).eval()
+        _perturb(mod, 300 + i)
+        x = torch.randn(B, T, dim)
+        fk, extra = {}, {}
+        if addmask:
+            am = 0.5 * torch.randn(B, 1, T, T)
+            fk["attention_mask"] = am
+            extra["attention_mask"] = am.numpy()
+        meta = dict(kind="quartet", dim=dim, heads=heads, use_quartet=uq, eps=cfg.score_norm_eps)
+        extra.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
+        _save(name, _run(mod, x, fk, extra))
+
+
+def sdpa_cases():
+    cases = [("sdpa_tiny", 64, 4, 2, 8, False), ("sdpa_mid_causal", 96, 3, 2, 33, True),
+             ("sdpa_n196", 128, 2, 1, 196, False)]
+    for i, (name, dim, heads, B, N, causal) in enumerate(cases):
+        torch.manual_seed(400 + i)
+        mod = BaselineMSA(dim, heads).eval()
+        x = torch.randn(B, N, dim)
+        fk, extra = {}, {}
+        if causal:
+            mask = torch.tril(torch.ones(N, N)).view(1, 1, N, N)
+            fk["attn_mask"] = mask
+            extra["attn_mask"] = mask.numpy()
+        meta = dict(kind="sdpa", dim=dim, heads=heads)
+        extra.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
+        _save(name, _run(mod, x, fk, extra))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    edgewise_cases()
+    multihop_cases()
+    quartet_cases()
+    sdpa_cases()
