@@ -1,0 +1,215 @@
+/*
+ * mopk.h -- C ABI of libmopk.so, the MI355X (gfx950) MoP-attention kernel library.
+ *
+ * The reference (Eran-BA/MoP) is pure PyTorch and has no FFI of its own; the
+ * drop-in boundary is the nn.Module surface (mop_amd/nn mirrors it).  This
+ * header is the boundary BELOW those modules: one entry point per reference
+ * attention core, each citing the reference code it replaces.  Plain pointers,
+ * sizes and element strides only; no torch types.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer unless stated; the caller owns every
+ *    buffer (inputs, outputs, `saved`, `workspace`); the library never
+ *    allocates or frees device memory and keeps no state between calls.
+ *  - Kernels are enqueued on `stream` (a hipStream_t passed as void*); no call
+ *    synchronises the host.  All entry points are graph-capturable.
+ *  - Strides are in ELEMENTS of the tensor's dtype; the innermost (dk) dimension
+ *    must be contiguous.
+ *  - Return value: 0 = ok, negative = MopkStatus; mopk_strerror() names it.
+ *  - `*_part` outputs are per-batch partial sums with leading dimension B; the
+ *    caller reduces them over dim 0 (keeps the kernels free of global atomics
+ *    and bit-reproducible).
+ */
+#ifndef MOPK_H
+#define MOPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOPK_VERSION 100 /* 0.1.0 */
+
+typedef enum MopkStatus {
+    MOPK_OK = 0,
+    MOPK_ERR_BAD_SHAPE = -1,    /* non-positive or unsupported dimension */
+    MOPK_ERR_BAD_ARG = -2,      /* null pointer / bad stride / bad enum */
+    MOPK_ERR_UNSUPPORTED = -3,  /* variant not implemented by the requested path */
+    MOPK_ERR_LAUNCH = -4,       /* hipGetLastError() != hipSuccess after a launch */
+    MOPK_ERR_NO_DEVICE = -5     /* no gfx950 device visible */
+} MopkStatus;
+
+typedef enum MopkDtype { MOPK_F32 = 0, MOPK_BF16 = 1 } MopkDtype;
+
+/* Arithmetic of the contractions.  FP32: exact fp32 FMA accumulation (parity
+ * <= 1e-3 vs the reference CPU path, in practice ~1e-5).  BF16: bf16 MFMA
+ * operands, fp32 accumulate, fp32 softmax/log/LSE/sigmoid (parity <= 1e-2). */
+typedef enum MopkPrecision { MOPK_PREC_FP32 = 0, MOPK_PREC_BF16 = 1 } MopkPrecision;
+
+/* Which implementation to run.  AUTO picks FUSED when the shape is supported
+ * by the fused gfx950 kernels and GENERIC (multi-kernel, any shape) otherwise. */
+typedef enum MopkPath { MOPK_PATH_AUTO = 0, MOPK_PATH_GENERIC = 1, MOPK_PATH_FUSED = 2 } MopkPath;
+
+/* A (B,H,N,dk) tensor view: element (b,h,n,d) at ptr + b*sb + h*sh + n*sn + d. */
+typedef struct MopkView4 {
+    void *ptr;
+    int64_t sb, sh, sn;
+} MopkView4;
+
+/* A per-view (V,B,H,N,dk) tensor view; sv == 0 means "one tensor shared by all views". */
+typedef struct MopkView5 {
+    void *ptr;
+    int64_t sv, sb, sh, sn;
+} MopkView5;
+
+/* --------------------------------------------------------------------------
+ * EdgewiseMSA attention core, low-rank gate head.
+ * Replaces reference mop/models/attention_variants.py:
+ *   EdgewiseMSA.forward :500-562 (scores, per-view softmax, chain products,
+ *   log features, gate head :319-331, score-space mix, re-normalise, value
+ *   aggregation + transport) for attn_mask=None, no lens banks, dropout 0.
+ * The qkv / proj Linear layers (:459, :564) stay outside (hipBLASLt GEMMs).
+ *
+ * Scale folding (verified identity):
+ *   S_v = ((q * q_scale_v) (k * k_scale_v)^T) / sqrt(dk) = ((q * sqk_v) k^T),
+ *   sqk_v = q_scale_v * k_scale_v / sqrt(dk).
+ * For share_qkv=False pass per-view q/k (sv != 0) and sqk = 1/sqrt(dk).
+ * -------------------------------------------------------------------------- */
+typedef struct MopkEdgewiseArgs {
+    int32_t B, H, N, dk;
+    int32_t V;          /* number of score views (>= 2)            :362 */
+    int32_t r;          /* gate_rank                               :277 */
+    int32_t io_dtype;   /* MopkDtype of q,k,v,y,dy,dq,dk,dv        */
+    int32_t precision;  /* MopkPrecision                           */
+    int32_t path;       /* MopkPath                                */
+    float beta_not;     /* :361, used at :546 */
+
+    MopkView5 q, k;          /* per-view (sv!=0) or shared (sv==0) queries / keys  :461-470 */
+    MopkView4 v0, vL;        /* values of view 0 and of the last view :553-557 (before v_scale) */
+    const float *sqk;        /* (V,H,dk) fp32, see above */
+    const float *vs0, *vsL;  /* (H,dk) fp32: v_scale[0], v_scale[V-1] (ones when unshared) */
+    const float *Wr, *br;    /* edge_head.row_proj weight (4r, 2V+2) / bias (4r)  :277 */
+    const float *Wc, *bc;    /* edge_head.col_proj                                 :278 */
+    const float *chain_logit;/* chain_value_logit, 1 fp32 on device                :451 */
+
+    MopkView4 y;             /* out: (B,H,N,dk) view of the (B,N,D) tensor fed to proj :563 */
+
+    void *saved;             /* out (fwd) / in (bwd): mopk_edgewise_saved_bytes() bytes */
+    void *workspace;         /* scratch: mopk_edgewise_workspace_bytes() bytes */
+
+    /* ---- backward only (ignored by _fwd) ---- */
+    MopkView4 dy;            /* in : dL/dy, same geometry as y */
+    MopkView5 dq, dk_;       /* out: dL/dq, dL/dk; sv==0 -> summed over views */
+    MopkView4 dv0, dvL;      /* out: dL/dv0, dL/dvL (v_scale applied); dv0.ptr == dvL.ptr -> their sum is written once */
+    float *dsqk_part;        /* out: (B,V,H,dk) */
+    float *dvs0_part, *dvsL_part; /* out: (B,H,dk) */
+    float *dWr, *dbr, *dWc, *dbc; /* out: (4r,2V+2),(4r),(4r,2V+2),(4r) -- fully reduced */
+    float *dlogit_part;      /* out: (B,H) */
+} MopkEdgewiseArgs;
+
+size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a);
+size_t mopk_edgewise_workspace_bytes(const MopkEdgewiseArgs *a);
+int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream);
+int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream);
+
+/* --------------------------------------------------------------------------
+ * MultiHopMSA (dual-path, scalar gates) attention core.
+ * Replaces reference mop/models/attention_variants.py:200-229
+ * (and experiments/cifar10_twohop_gates.py:55-99 `dual_path_mix`).
+ * mask: optional uint8 (1 = keep, 0 = blocked), element (b,h,i,j) at
+ * mask + b*mask_sb + h*mask_sh + i*mask_si + j (strides may be 0 to broadcast);
+ * `causal` != 0 adds the lower-triangular mask without reading memory.
+ * -------------------------------------------------------------------------- */
+typedef struct MopkDualPathArgs {
+    int32_t B, H, N, dk;
+    int32_t hops;            /* >= 2  :174 */
+    int32_t io_dtype, precision, path;
+    int32_t causal;
+    float g_and, g_or, g_not, g_chain; /* python-float gates :188 */
+    float beta_not;
+    MopkView4 q1, k1, v1, q2, k2, v2;
+    const uint8_t *mask;
+    int64_t mask_sb, mask_sh, mask_si;
+    const float *chain_logit;
+    MopkView4 y;
+    void *saved, *workspace;
+    /* backward */
+    MopkView4 dy, dq1, dk1, dv1, dq2, dk2, dv2;
+    float *dlogit_part;      /* (B,H) */
+} MopkDualPathArgs;
+
+size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a);
+size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a);
+int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream);
+int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream);
+
+/* --------------------------------------------------------------------------
+ * Quartet CausalSelfAttention core.
+ * Replaces reference mop/models/quartet_attn_patch.py:88-121 (scores, row
+ * z-norm with unbiased std over the full row, product mix, causal mask,
+ * additive attention_mask, softmax, AV).  use_quartet==0 -> :108-110.
+ * add_mask: optional fp32 additive mask, element (b,h,i,j) at
+ * add_mask + b*am_sb + h*am_sh + i*am_si + j.
+ * -------------------------------------------------------------------------- */
+typedef struct MopkQuartetArgs {
+    int32_t B, H, T, dh;
+    int32_t io_dtype, precision, path;
+    int32_t use_quartet;
+    float eps;               /* score_norm_eps :31 */
+    MopkView4 q, k, v, q2, k2;
+    const float *mixture;        /* 1 fp32 on device :52 */
+    const float *quartet_scale;  /* 1 fp32 on device :55 */
+    const float *add_mask;
+    int64_t am_sb, am_sh, am_si;
+    MopkView4 y;
+    float *attn;             /* optional out (B,H,T,T) fp32 for need_weights=True :125 */
+    void *saved, *workspace;
+    /* backward */
+    MopkView4 dy, dq, dk_, dv, dq2, dk2;
+    float *dmixture_part, *dqscale_part; /* (B,H) */
+} MopkQuartetArgs;
+
+size_t mopk_quartet_saved_bytes(const MopkQuartetArgs *a);
+size_t mopk_quartet_workspace_bytes(const MopkQuartetArgs *a);
+int mopk_quartet_fwd(const MopkQuartetArgs *a, void *stream);
+int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream);
+
+/* --------------------------------------------------------------------------
+ * Plain scaled-dot-product attention core.
+ * Replaces BaselineMSA.forward attention_variants.py:42-46, MSA.forward
+ * components.py:61-64 and MultiheadSelfAttention.forward whisper_mop.py:163-175.
+ * -------------------------------------------------------------------------- */
+typedef struct MopkSdpaArgs {
+    int32_t B, H, N, dk;
+    int32_t io_dtype, precision, path;
+    int32_t causal;
+    MopkView4 q, k, v;
+    const uint8_t *mask;     /* optional, 1 = keep */
+    int64_t mask_sb, mask_sh, mask_si;
+    const float *bias;       /* optional additive fp32 */
+    int64_t bias_sb, bias_sh, bias_si;
+    MopkView4 y;
+    void *saved, *workspace;
+    MopkView4 dy, dq, dk_, dv;
+} MopkSdpaArgs;
+
+size_t mopk_sdpa_saved_bytes(const MopkSdpaArgs *a);
+size_t mopk_sdpa_workspace_bytes(const MopkSdpaArgs *a);
+int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream);
+int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream);
+
+/* -------------------------------------------------------------------------- */
+int mopk_version(void);
+const char *mopk_strerror(int status);
+/* 1 if the fused gfx950 kernels cover this Edgewise shape (N, dk, V, r). */
+int mopk_edgewise_fused_supported(const MopkEdgewiseArgs *a);
+/* name of the dominant kernel the last edgewise fwd/bwd on this thread launched
+ * (static string; used by bench.py to match rocprofv3 kernel-trace rows). */
+const char *mopk_edgewise_dominant_kernel(const MopkEdgewiseArgs *a, int backward);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPK_H */

@@ -1,0 +1,159 @@
+// Generic strided batched GEMM used by the multi-kernel ("generic") path.
+//   C[b0,b1] = alpha * op(A)[b0,b1] * op(B)[b0,b1] + beta * C[b0,b1]
+// fp32 in global memory; arithmetic is either exact fp32 FMA (PREC_FP32) or
+// bf16 MFMA 16x16x32 with fp32 accumulation (PREC_BF16: operands are rounded to
+// bf16 while being staged into LDS).  Any M/N/K/strides; edges are zero-filled.
+// This is the any-shape fallback and the fp32-exact path -- the NS hot shape
+// runs the fused kernels in edgewise_fused.hip instead.
+#pragma once
+#include "common.h"
+
+namespace mopk {
+
+struct GemmDesc {
+    int M, N, K, nb0, nb1;
+    const float *A;
+    int64_t a_rs, a_cs, a_b0, a_b1;  // A(m,k)
+    const float *B;
+    int64_t b_rs, b_cs, b_b0, b_b1;  // B(k,n)
+    float *C;
+    int64_t c_rs, c_b0, c_b1;        // C(m,n), n contiguous
+    float alpha;
+    const float *alpha_dev;          // optional extra device-side scalar factor
+    float beta;
+};
+
+constexpr int GB_M = 64, GB_N = 64, GB_K = 32;
+
+template <bool MFMA, bool A_KC, bool B_NC>
+__global__ __launch_bounds__(256) void bgemm_kernel(GemmDesc d) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * GB_K * (GB_M + 4)];
+    const int t = threadIdx.x;
+    const int bz = blockIdx.z;
+    const int i0 = bz / d.nb1, i1 = bz % d.nb1;
+    const float *A = d.A + i0 * d.a_b0 + i1 * d.a_b1;
+    const float *B = d.B + i0 * d.b_b0 + i1 * d.b_b1;
+    float *C = d.C + i0 * d.c_b0 + i1 * d.c_b1;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+
+    float *As = smem;                           // fp32: [GB_K][GB_M+4]
+    float *Bs = smem + GB_K * (GB_M + 4);       // fp32: [GB_K][GB_N+4]
+    unsigned short *Ah = (unsigned short *)smem;            // bf16: [GB_M][GB_K+8]
+    unsigned short *Bh = Ah + GB_M * (GB_K + 8);            // bf16: [GB_N][GB_K+8]
+
+    float acc[4][4];
+    f32x4 macc[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) macc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int tx = t & 15, ty = t >> 4;
+
+    for (int k0 = 0; k0 < d.K; k0 += GB_K) {
+        // ---- stage A tile (GB_M x GB_K) and B tile (GB_K x GB_N) ----
+#pragma unroll
+        for (int i = 0; i < (GB_M * GB_K) / 256; ++i) {
+            int idx = t + 256 * i;
+            int m, k;
+            if (A_KC) { k = idx % GB_K; m = idx / GB_K; } else { m = idx % GB_M; k = idx / GB_M; }
+            float v = 0.f;
+            if (m0 + m < d.M && k0 + k < d.K) v = A[(int64_t)(m0 + m) * d.a_rs + (int64_t)(k0 + k) * d.a_cs];
+            if (MFMA) Ah[m * (GB_K + 8) + k] = f2bf(v); else As[k * (GB_M + 4) + m] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < (GB_N * GB_K) / 256; ++i) {
+            int idx = t + 256 * i;
+            int n, k;
+            if (B_NC) { n = idx % GB_N; k = idx / GB_N; } else { k = idx % GB_K; n = idx / GB_K; }
+            float v = 0.f;
+            if (n0 + n < d.N && k0 + k < d.K) v = B[(int64_t)(k0 + k) * d.b_rs + (int64_t)(n0 + n) * d.b_cs];
+            if (MFMA) Bh[n * (GB_K + 8) + k] = f2bf(v); else Bs[k * (GB_N + 4) + n] = v;
+        }
+        __syncthreads();
+        if (MFMA) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = *(const bf16x8 *)&Ah[(wm * 32 + i * 16 + (lane & 15)) * (GB_K + 8) + 8 * (lane >> 4)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = *(const bf16x8 *)&Bh[(wn * 32 + j * 16 + (lane & 15)) * (GB_K + 8) + 8 * (lane >> 4)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    macc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], macc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < GB_K; ++k) {
+                const float4 a4 = *(const float4 *)&As[k * (GB_M + 4) + ty * 4];
+                const float4 b4 = *(const float4 *)&Bs[k * (GB_N + 4) + tx * 4];
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+    float alpha = d.alpha;
+    if (d.alpha_dev) alpha *= *d.alpha_dev;
+    if (MFMA) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+                    int n = n0 + wn * 32 + j * 16 + (lane & 15);
+                    if (m < d.M && n < d.N) {
+                        float *p = C + (int64_t)m * d.c_rs + n;
+                        float v = alpha * macc[i][j][r];
+                        if (d.beta != 0.f) v += d.beta * *p;
+                        *p = v;
+                    }
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+                if (m < d.M && n < d.N) {
+                    float *p = C + (int64_t)m * d.c_rs + n;
+                    float v = alpha * acc[i][j];
+                    if (d.beta != 0.f) v += d.beta * *p;
+                    *p = v;
+                }
+            }
+    }
+}
+
+inline int bgemm(const GemmDesc &d, bool mfma, hipStream_t st) {
+    if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.nb0 * d.nb1 <= 0) return MOPK_ERR_BAD_SHAPE;
+    dim3 grid((d.N + GB_N - 1) / GB_N, (d.M + GB_M - 1) / GB_M, d.nb0 * d.nb1);
+    const bool akc = d.a_cs == 1, bnc = d.b_cs == 1;
+#define MOPK_BG(MF, AK, BN_) hipLaunchKernelGGL((bgemm_kernel<MF, AK, BN_>), grid, dim3(256), 0, st, d)
+    if (mfma) {
+        if (akc && bnc) MOPK_BG(true, true, true); else if (akc) MOPK_BG(true, true, false);
+        else if (bnc) MOPK_BG(true, false, true); else MOPK_BG(true, false, false);
+    } else {
+        if (akc && bnc) MOPK_BG(false, true, true); else if (akc) MOPK_BG(false, true, false);
+        else if (bnc) MOPK_BG(false, false, true); else MOPK_BG(false, false, false);
+    }
+#undef MOPK_BG
+    MOPK_CHECK_LAUNCH();
+    return MOPK_OK;
+}
+
+}  // namespace mopk

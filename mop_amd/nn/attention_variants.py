@@ -1,0 +1,270 @@
+"""Drop-in attention modules backed by libmopk (gfx950 HIP kernels).
+
+Same constructor signatures, forward signatures, parameter names/shapes and
+initialisation as reference `mop/models/attention_variants.py`, so reference
+checkpoints load with `load_state_dict` and call sites need no change:
+
+    BaselineMSA      <- attention_variants.py:23-48
+    MultiHopMSA      <- :163-231
+    EdgewiseGateHead <- :234-331   (parameter container; its arithmetic runs inside the kernels)
+    EdgewiseMSA      <- :334-564
+    UnifiedMSA       <- :567-629
+
+Only the Linear projections run in PyTorch (hipBLASLt); everything between the
+qkv projection and the output projection is one C-ABI call (mop_amd/ops.py).
+Variants the kernels do not cover yet raise NotImplementedError instead of
+silently decomposing: dense gate head / use_k3 (a8), lens banks (a11), masked
+Edgewise (NaN in the reference, SURVEY.md 8a note), CrossViewMixerMSA (8f rank 3).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+# gate order inside the low-rank head: 0=and 1=or 2=not 3=chain   (:284)
+_LOWRANK_PRESET = {
+    "and": (0,), "or": (1,), "not": (2,), "chain": (3,),
+    "nor": (2,), "xor": (1,),          # :292-297
+    "mix5": (0, 1, 2),                 # :302-308
+}
+_DENSE_PRESET = {"and": 0, "or": 1, "not": 2, "nor": 2, "xor": 1, "chain": 3}   # :259-272
+
+
+class EdgewiseGateHead(nn.Module):
+    """Parameters of the per-edge gate head (reference :234-309).
+
+    low-rank mode: row_proj / col_proj Conv1d(in_ch, 4*rank, 1) consumed by the
+    kernels as (4r, C) matrices.  dense mode: conv1 / [mid3] / conv2 are created
+    with the reference's names and presets so checkpoints load, but the dense
+    kernels are not built yet.
+    """
+
+    def __init__(self, in_ch: int, hidden: int = 16, use_k3: bool = False, gate_mode: str = "dense",
+                 gate_rank: int = 4, gate_init: str = "neutral"):
+        super().__init__()
+        self.use_k3 = bool(use_k3)
+        self.gate_mode = str(gate_mode)
+        self.gate_rank = int(gate_rank)
+        self.gate_init = str(gate_init)
+        if self.gate_mode == "dense":
+            self.conv1 = nn.Conv2d(in_ch, hidden, kernel_size=1, bias=True)
+            self.act = nn.GELU(approximate="tanh")
+            if self.use_k3:
+                self.mid3 = nn.Conv2d(hidden, hidden, kernel_size=3, padding=1, bias=True)
+            self.conv2 = nn.Conv2d(hidden, 4, kernel_size=1, bias=True)
+            with torch.no_grad():
+                self.conv2.bias.fill_(-5.0)
+                if self.gate_init in _DENSE_PRESET:
+                    self.conv2.bias[_DENSE_PRESET[self.gate_init]] = 2.0
+        else:
+            r = self.gate_rank
+            self.row_proj = nn.Conv1d(in_ch, 4 * r, kernel_size=1, bias=True)
+            self.col_proj = nn.Conv1d(in_ch, 4 * r, kernel_size=1, bias=True)
+            c = math.sqrt(2.0 / max(1, r))
+            with torch.no_grad():
+                self.row_proj.bias.zero_()
+                self.col_proj.bias.zero_()
+                for g in _LOWRANK_PRESET.get(self.gate_init, ()):
+                    self.row_proj.bias[g * r:(g + 1) * r] = c
+                    self.col_proj.bias[g * r:(g + 1) * r] = c
+
+    def forward(self, feat: torch.Tensor) -> torch.Tensor:  # pragma: no cover - never materialised
+        raise NotImplementedError(
+            "EdgewiseGateHead is evaluated inside the fused kernels from row/col means; the "
+            "(BH,C,N,N) feature stack of the reference is never built")
+
+
+class EdgewiseMSA(nn.Module):
+    def __init__(self, dim: int, heads: int = 4, attn_drop: float = 0.0, proj_drop: float = 0.0,
+                 beta_not: float = 0.5, use_k3: bool = False, n_views: int = 2, share_qkv: bool = False,
+                 gate_mode: str = "dense", gate_rank: int = 4, gate_init: str = "neutral",
+                 use_lens_bank: bool = False, lens_kernel_size: int = 3,
+                 lens_dilations: Optional[Tuple[int, ...]] = None, use_lens_bank_qk: bool = False,
+                 lens_qk_kernel_size: int = 3, lens_qk_dilations: Optional[Tuple[int, ...]] = None,
+                 lens_qk_causal: bool = False):
+        super().__init__()
+        assert dim % heads == 0
+        self.h, self.dk = heads, dim // heads
+        self.beta_not = beta_not
+        self.n_views = max(2, int(n_views))
+        self.share_qkv = bool(share_qkv)
+        self.use_lens_bank = bool(use_lens_bank)
+        self.lens_kernel_size = int(lens_kernel_size)
+        self.lens_dilations = tuple(lens_dilations) if lens_dilations is not None else (1, 2)
+        self.use_lens_bank_qk = bool(use_lens_bank_qk)
+        self.lens_qk_kernel_size = int(lens_qk_kernel_size)
+        self.lens_qk_dilations = tuple(lens_qk_dilations) if lens_qk_dilations is not None else (1, 2)
+        self.lens_qk_causal = bool(lens_qk_causal)
+        if self.use_lens_bank_qk and not self.share_qkv:
+            raise ValueError("use_lens_bank_qk=True requires share_qkv=True for now")
+        V, H, dk = self.n_views, self.h, self.dk
+        if self.share_qkv:
+            self.qkv = nn.Linear(dim, 3 * dim, bias=False)
+            self.q_scale = nn.Parameter(torch.ones(V, H, 1, dk))
+            self.k_scale = nn.Parameter(torch.ones(V, H, 1, dk))
+            self.v_scale = nn.Parameter(torch.ones(V, H, 1, dk))
+        else:
+            self.qkv_list = nn.ModuleList(nn.Linear(dim, 3 * dim, bias=False) for _ in range(V))
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj_drop = nn.Dropout(proj_drop)
+        num_s = len(self.lens_qk_dilations) if self.use_lens_bank_qk else V
+        in_ch = 2 * num_s + 2
+        if self.use_lens_bank_qk:
+            k = self.lens_qk_kernel_size
+
+            def dw(d):
+                pad = 0 if self.lens_qk_causal else d * (k - 1) // 2
+                return nn.Conv1d(dk, dk, k, padding=pad, dilation=d, groups=dk, bias=False)
+
+            self.q_lens = nn.ModuleList(dw(d) for d in self.lens_qk_dilations)
+            self.k_lens = nn.ModuleList(dw(d) for d in self.lens_qk_dilations)
+            self._lens_qk_num = num_s
+        if self.use_lens_bank:
+            self.lens_bank = nn.ModuleList(
+                nn.Conv2d(num_s, num_s, self.lens_kernel_size, padding=d, dilation=d, groups=num_s, bias=False)
+                for d in self.lens_dilations)
+            in_ch += num_s * len(self.lens_dilations)
+        self.edge_head = EdgewiseGateHead(in_ch=in_ch, hidden=16, use_k3=use_k3, gate_mode=gate_mode,
+                                          gate_rank=gate_rank, gate_init=gate_init)
+        self.chain_value_logit = nn.Parameter(torch.tensor(-2.0))
+
+    def _check_supported(self, attn_mask):
+        if attn_mask is not None:
+            raise NotImplementedError(
+                "EdgewiseMSA with attn_mask: the reference returns NaN for any blocking mask "
+                "(SURVEY.md 8a note); not supported by the kernels")
+        if self.edge_head.gate_mode != "lowrank":
+            raise NotImplementedError("EdgewiseMSA gate_mode='dense' kernels are not built yet (8f rank 2)")
+        if self.use_lens_bank or self.use_lens_bank_qk:
+            raise NotImplementedError("EdgewiseMSA lens banks are not built yet (8f rank 2)")
+        if self.training and (self.attn_drop.p > 0):
+            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_supported(attn_mask)
+        B, N, D = x.shape
+        H, dk, V = self.h, self.dk, self.n_views
+        inv = 1.0 / math.sqrt(dk)
+        if self.share_qkv:
+            qkv = self.qkv(x).view(B, N, 1, 3, H, dk)
+            sqk = (self.q_scale * self.k_scale).squeeze(2) * inv          # (V,H,dk)
+            vs0, vsL = self.v_scale[0, :, 0], self.v_scale[V - 1, :, 0]   # (H,dk)
+        else:
+            w = torch.cat([lin.weight for lin in self.qkv_list], dim=0)   # one GEMM for all views
+            qkv = F.linear(x, w).view(B, N, V, 3, H, dk)
+            sqk = torch.full((V, H, dk), inv, device=x.device, dtype=torch.float32)
+            vs0 = vsL = torch.ones(H, dk, device=x.device, dtype=torch.float32)
+        eh = self.edge_head
+        y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,
+                                      eh.col_proj.weight.squeeze(-1), eh.col_proj.bias,
+                                      self.chain_value_logit, float(self.beta_not), V)
+        return self.proj_drop(self.proj(y))
+
+
+class BaselineMSA(nn.Module):
+    def __init__(self, dim: int, heads: int = 4, attn_drop: float = 0.0, proj_drop: float = 0.0):
+        super().__init__()
+        assert dim % heads == 0
+        self.h, self.dk = heads, dim // heads
+        self.qkv = nn.Linear(dim, 3 * dim, bias=False)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, N, D = x.shape
+        qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
+        y = ops.sdpa_core(qkv, attn_mask)
+        return self.proj_drop(self.proj(y))
+
+
+class MultiHopMSA(nn.Module):
+    """Dual-path logits with scalar gates; default gates give softmax(S1+S2) (:209-221)."""
+
+    def __init__(self, dim: int, heads: int = 4, attn_drop: float = 0.0, proj_drop: float = 0.0,
+                 beta_not: float = 0.5, gates: Optional[Dict[str, float]] = None, hops: int = 3):
+        super().__init__()
+        assert dim % heads == 0
+        assert hops >= 2
+        self.h, self.dk, self.hops = heads, dim // heads, int(hops)
+        self.qkv1 = nn.Linear(dim, 3 * dim, bias=False)
+        self.qkv2 = nn.Linear(dim, 3 * dim, bias=False)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.beta_not = float(beta_not)
+        self.gates = gates or dict(and_=1.0, or_=0.0, not_=0.0, chain=0.0, base=1.0)
+        self.chain_value_logit = nn.Parameter(torch.tensor(-2.0))
+
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, N, D = x.shape
+        qkv1 = self.qkv1(x).view(B, N, 3, self.h, self.dk)
+        qkv2 = self.qkv2(x).view(B, N, 3, self.h, self.dk)
+        g = self.gates
+        y = ops.dualpath_core(qkv1, qkv2, self.chain_value_logit, g.get("and_", 1.0), g.get("or_", 0.0),
+                              g.get("not_", 0.0), g.get("chain", 0.0), self.beta_not, self.hops, attn_mask)
+        return self.proj_drop(self.proj(y))
+
+
+class CrossViewMixerMSA(nn.Module):
+    """Parameter-compatible placeholder (reference :51-156); kernels are SURVEY.md 8f rank 3."""
+
+    def __init__(self, dim: int, heads: int = 4, attn_drop: float = 0.0, proj_drop: float = 0.0,
+                 use_transpose_cues: bool = True, t1: float = 0.0, t2: float = 0.0,
+                 enable_per_key_prior: bool = False, prior_weight: float = 0.5,
+                 anchor_mode: str = "argmax_row_sum", fixed_k_star: int = 0):
+        super().__init__()
+        assert dim % heads == 0
+        self.h, self.dk = heads, dim // heads
+        self.qkv1 = nn.Linear(dim, 3 * dim, bias=False)
+        self.qkv2 = nn.Linear(dim, 3 * dim, bias=False)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.mix = nn.Parameter(torch.eye(2))
+        self.use_transpose_cues, self.t1, self.t2 = bool(use_transpose_cues), float(t1), float(t2)
+        self.enable_per_key_prior, self.prior_weight = bool(enable_per_key_prior), float(prior_weight)
+        self.anchor_mode, self.fixed_k_star = str(anchor_mode), int(fixed_k_star)
+
+    def forward(self, x, attn_mask=None):
+        raise NotImplementedError("CrossViewMixerMSA kernels are not built yet (SURVEY.md 8f rank 3)")
+
+
+class UnifiedMSA(nn.Module):
+    """mode 'A'/'B' -> BaselineMSA, 'C' -> CrossViewMixerMSA, 'D' -> MultiHopMSA, 'E' -> EdgewiseMSA.
+    Like the reference (:609-622), mode E does not forward the lens kwargs."""
+
+    def __init__(self, mode: str, dim: int, heads: int = 4, **kwargs):
+        super().__init__()
+        mode = str(mode).upper()
+        self.mode = mode
+        kw = kwargs.get
+        if mode in ("A", "B"):
+            self.impl = BaselineMSA(dim, heads, kw("attn_drop", 0.0), kw("proj_drop", 0.0))
+        elif mode == "C":
+            self.impl = CrossViewMixerMSA(
+                dim, heads, kw("attn_drop", 0.0), kw("proj_drop", 0.0),
+                use_transpose_cues=kw("use_transpose_cues", True), t1=kw("t1", 0.0), t2=kw("t2", 0.0),
+                enable_per_key_prior=kw("enable_per_key_prior", False), prior_weight=kw("prior_weight", 0.5),
+                anchor_mode=kw("anchor_mode", "argmax_row_sum"), fixed_k_star=kw("fixed_k_star", 0))
+        elif mode == "D":
+            self.impl = MultiHopMSA(dim, heads, kw("attn_drop", 0.0), kw("proj_drop", 0.0),
+                                    beta_not=kw("beta_not", 0.5), gates=kw("gates", None), hops=kw("hops", 3))
+        elif mode == "E":
+            self.impl = EdgewiseMSA(dim, heads, kw("attn_drop", 0.0), kw("proj_drop", 0.0),
+                                    beta_not=kw("beta_not", 0.5), use_k3=kw("use_k3", False),
+                                    n_views=kw("n_views", 2), share_qkv=kw("share_qkv", False),
+                                    gate_mode=kw("gate_mode", "dense"), gate_rank=kw("gate_rank", 4),
+                                    gate_init=kw("gate_init", "neutral"))
+        else:
+            raise ValueError(f"Unknown attention mode: {mode}")
+
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.impl(x, attn_mask)

@@ -1,0 +1,92 @@
+"""Host-side surface (no GPU): constructor signatures, state_dict keys/shapes and init presets
+match what the reference produced (golden param sets came from the reference's own modules)."""
+import inspect
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+
+@pytest.mark.parametrize("name", golden_names("ew_"))
+def test_edgewise_state_dict_matches_reference(name):
+    from mop_amd.nn import EdgewiseMSA
+    d, params, gref, meta = load_golden(name)
+    m = EdgewiseMSA(meta["dim"], meta["heads"], n_views=meta["n_views"], share_qkv=bool(meta["share_qkv"]),
+                    gate_mode="lowrank", gate_rank=meta["gate_rank"])
+    sd = m.state_dict()
+    assert set(sd) == set(params)
+    for k, v in params.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+
+
+def test_edgewise_ctor_signature_is_the_reference_one():
+    from mop_amd.nn import EdgewiseMSA
+    names = list(inspect.signature(EdgewiseMSA.__init__).parameters)[1:]
+    assert names == ["dim", "heads", "attn_drop", "proj_drop", "beta_not", "use_k3", "n_views", "share_qkv",
+                     "gate_mode", "gate_rank", "gate_init", "use_lens_bank", "lens_kernel_size", "lens_dilations",
+                     "use_lens_bank_qk", "lens_qk_kernel_size", "lens_qk_dilations", "lens_qk_causal"]
+    d = {k: p.default for k, p in inspect.signature(EdgewiseMSA.__init__).parameters.items() if k != "self"}
+    assert d["heads"] == 4 and d["beta_not"] == 0.5 and d["n_views"] == 2 and d["gate_mode"] == "dense"
+    assert d["gate_rank"] == 4 and d["gate_init"] == "neutral" and d["share_qkv"] is False
+
+
+@pytest.mark.parametrize("init,gates", [("and", [0]), ("or", [1]), ("not", [2]), ("chain", [3]), ("nor", [2]),
+                                         ("xor", [1]), ("mix5", [0, 1, 2]), ("neutral", [])])
+def test_lowrank_gate_presets(init, gates):
+    from mop_amd.nn import EdgewiseGateHead
+    r = 4
+    h = EdgewiseGateHead(12, gate_mode="lowrank", gate_rank=r, gate_init=init)
+    c = math.sqrt(2.0 / r)
+    exp = np.zeros(4 * r, dtype=np.float32)
+    for g in gates:
+        exp[g * r:(g + 1) * r] = c
+    np.testing.assert_allclose(h.row_proj.bias.detach().numpy(), exp, rtol=1e-6)
+    np.testing.assert_allclose(h.col_proj.bias.detach().numpy(), exp, rtol=1e-6)
+
+
+def test_dense_head_params_and_presets():
+    from mop_amd.nn import EdgewiseMSA
+    m = EdgewiseMSA(64, 4, use_k3=True, n_views=3, gate_mode="dense", gate_init="or")
+    sd = m.state_dict()
+    assert tuple(sd["edge_head.conv1.weight"].shape) == (16, 8, 1, 1)
+    assert tuple(sd["edge_head.mid3.weight"].shape) == (16, 16, 3, 3)
+    assert tuple(sd["edge_head.conv2.weight"].shape) == (4, 16, 1, 1)
+    np.testing.assert_allclose(sd["edge_head.conv2.bias"].numpy(), [-5, 2, -5, -5])
+    assert "qkv_list.2.weight" in sd and "qkv.weight" not in sd
+
+
+def test_n_views_floor_and_lens_validation():
+    from mop_amd.nn import EdgewiseMSA
+    assert EdgewiseMSA(32, 2, n_views=1, gate_mode="lowrank").n_views == 2
+    with pytest.raises(ValueError):
+        EdgewiseMSA(32, 2, use_lens_bank_qk=True, share_qkv=False)
+    m = EdgewiseMSA(64, 4, share_qkv=True, gate_mode="lowrank", gate_rank=2, use_lens_bank=True,
+                    use_lens_bank_qk=True, lens_qk_causal=True)
+    sd = m.state_dict()
+    assert tuple(sd["q_lens.0.weight"].shape) == (16, 1, 3) and tuple(sd["lens_bank.1.weight"].shape) == (2, 1, 3, 3)
+    assert tuple(sd["edge_head.row_proj.weight"].shape) == (8, 2 * 2 + 2 + 2 * 2, 1)
+
+
+def test_unified_switch():
+    from mop_amd.nn import BaselineMSA, CrossViewMixerMSA, EdgewiseMSA, MultiHopMSA, UnifiedMSA
+    assert isinstance(UnifiedMSA("a", 64, 4).impl, BaselineMSA)
+    assert isinstance(UnifiedMSA("B", 64, 4).impl, BaselineMSA)
+    assert isinstance(UnifiedMSA("C", 64, 4).impl, CrossViewMixerMSA)
+    assert isinstance(UnifiedMSA("D", 64, 4, hops=2).impl, MultiHopMSA)
+    e = UnifiedMSA("E", 64, 4, n_views=5, share_qkv=True, gate_mode="lowrank", gate_rank=4, gate_init="mix5")
+    assert isinstance(e.impl, EdgewiseMSA) and "impl.q_scale" in e.state_dict()
+    with pytest.raises(ValueError):
+        UnifiedMSA("Z", 64)
+
+
+def test_unsupported_variants_raise_instead_of_falling_back():
+    from mop_amd.nn import EdgewiseMSA
+    x = torch.randn(1, 8, 64)
+    with pytest.raises(NotImplementedError):
+        EdgewiseMSA(64, 4, gate_mode="dense")(x)
+    with pytest.raises(NotImplementedError):
+        EdgewiseMSA(64, 4, gate_mode="lowrank", share_qkv=True)(x, attn_mask=torch.ones(8, 8))
