@@ -71,6 +71,39 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+# ---- optional kernel timing (bench.py): HIP events on the stream the kernels are launched on ----
+_TIMING = None  # dict name -> list[(start_event, stop_event)] when enabled
+
+
+def enable_timing(on: bool = True) -> None:
+    global _TIMING
+    _TIMING = {} if on else None
+
+
+def timing_results() -> dict:
+    """name -> list of elapsed milliseconds (call after torch.cuda.synchronize())."""
+    if _TIMING is None:
+        return {}
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in _TIMING.items()}
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()  # current stream == the stream passed to libmopk
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            self.b.record()
+            _TIMING.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 def _bytes(n: int, dev) -> torch.Tensor:
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
 
@@ -121,7 +154,9 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
-        L.check(lib.mopk_edgewise_lowrank_fwd(C.byref(a), _stream()), "mopk_edgewise_lowrank_fwd")
+        with _timed("edgewise_fwd"):
+            rc = lib.mopk_edgewise_lowrank_fwd(C.byref(a), _stream())
+        L.check(rc, "mopk_edgewise_lowrank_fwd")
         ctx.save_for_backward(qkv, saved, *f.values())
         ctx.meta = (beta_not, V, prec, path, r)
         return y.view(B, N, H * dk)
@@ -163,7 +198,9 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.dlogit_part = dlg.data_ptr()
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
-        L.check(lib.mopk_edgewise_lowrank_bwd(C.byref(a), _stream()), "mopk_edgewise_lowrank_bwd")
+        with _timed("edgewise_bwd"):
+            rc = lib.mopk_edgewise_lowrank_bwd(C.byref(a), _stream())
+        L.check(rc, "mopk_edgewise_lowrank_bwd")
         return (dqkv, dsqk.sum(0), dvs0.sum(0), dvsL.sum(0), dWr, dbr, dWc, dbc,
                 dlg.sum().reshape(()), None, None, None, None)
 
