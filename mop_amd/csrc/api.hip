@@ -6,6 +6,8 @@ size_t ew_generic_saved_bytes(const MopkEdgewiseArgs *a);
 size_t ew_generic_workspace_bytes(const MopkEdgewiseArgs *a);
 int ew_generic_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_generic_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
+int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
+int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 
 static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
     if (!a) return MOPK_ERR_BAD_ARG;
@@ -43,7 +45,7 @@ const char *mopk_strerror(int s) {
     }
 }
 
-int mopk_edgewise_fused_supported(const MopkEdgewiseArgs *a) { (void)a; return 0; }
+int mopk_edgewise_fused_supported(const MopkEdgewiseArgs *a) { return a ? ew_fused_fwd_supported(a) : 0; }
 
 const char *mopk_edgewise_dominant_kernel(const MopkEdgewiseArgs *a, int backward) {
     (void)a; (void)backward;
@@ -52,16 +54,18 @@ const char *mopk_edgewise_dominant_kernel(const MopkEdgewiseArgs *a, int backwar
 
 size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a) {
     if (!a || a->B <= 0 || a->H <= 0 || a->N <= 0 || a->dk <= 0 || a->V < 2 || a->r < 1) return 0;
+    if (a->path == MOPK_PATH_FUSED) return (size_t)a->B * a->H * a->N * a->dk * sizeof(float) + 256;  // w * y_chain
     return ew_generic_saved_bytes(a);
 }
 size_t mopk_edgewise_workspace_bytes(const MopkEdgewiseArgs *a) {
     if (!a || a->B <= 0 || a->H <= 0 || a->N <= 0 || a->dk <= 0 || a->V < 2 || a->r < 1) return 0;
+    if (a->path == MOPK_PATH_FUSED) return 256;
     return ew_generic_workspace_bytes(a);
 }
 int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, false);
     if (rc) return rc;
-    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    if (a->path == MOPK_PATH_FUSED) return ew_fused_fwd(a, (hipStream_t)stream);
     return ew_generic_fwd(a, (hipStream_t)stream);
 }
 int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream) {

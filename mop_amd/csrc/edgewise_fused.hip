@@ -1,0 +1,567 @@
+// EdgewiseMSA low-rank core -- fused gfx950 forward kernel (bf16 MFMA, fp32 accumulate).
+//
+// One workgroup per (batch, head); NT = ceil(N/32) waves, wave w owns queries
+// [32w, 32w+32).  Every N x N map lives on-chip only:
+//
+//   * "X layout": a wave holds the TRANSPOSED row block M^T[:, I] of an N x N matrix M as
+//     NT accumulator tiles of v_mfma_f32_32x32x16_bf16 (lane = query i in I, registers =
+//     key j).  Row softmax, row means, log, the score mix and the final softmax are then
+//     per-lane register loops (+ one lane-half exchange); no LDS round trip.
+//   * chain products (reference attention_variants.py:508-515) run transposed:
+//         (T A_m)^T[:, I] = A_m^T . T^T[:, I]
+//     the previous product is the B operand straight from its accumulator registers
+//     (cdna guide: "accumulator tile as the next MFMA's operand"), A_m^T is staged once per
+//     step in LDS (k-permuted columns so one ds_read_b128 matches the accumulator k order).
+//   * C<- is reduced to its row/col log-means and dropped; C-> stays in registers for the
+//     mix, the transport term y_chain = A_0(A_1(..A_{V-1} v_L)) is evaluated as C-> v_L.
+//   * gate logits Z_g = a_g^T b_g (rank r <= 4) are ONE MFMA per (tile, gate) with hi/lo bf16
+//     splits of a and b packed into the K=16 slots, i.e. ~fp32-accurate.
+//
+// HBM traffic per (b,h): q,k,v in + y out (~100 KB) for 0.9 GFLOP -> MFMA/VALU bound.
+#include "common.h"
+
+namespace mopk {
+
+constexpr float EPSC = 1e-6f;   // attention_variants.py:516
+constexpr int BTS = 24;         // bT row stride (ushorts): 16 k-slots + 8 pad (48 B, 16-B aligned)
+
+__host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int kperm16(int k) { return (k & 3) | ((k & 4) << 1) | ((k & 8) >> 1); }
+__device__ __forceinline__ int tile_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+template <int NT, int DK>
+struct FusedCfg {
+    static constexpr int NP = NT * 32, LDA = NP + 8, LDK = DK + 8, KS = DK / 16;
+    static constexpr int DT = DK >= 32 ? DK / 32 : 1, DP = DT * 32;
+    static constexpr int R_BYTES = imax(NP * LDA * 2, 2 * DP * LDA * 2 + 4 * NP * BTS * 2);
+    static constexpr int K_BYTES = NP * LDK * 2;
+    // fp32 scratch (floats): sqk[8][DK] qbar kbar vs0 vsL [DK] | rCr rCl cCr cCl [NP] | colpart[NT][NP] | rS cS [V][NP] | wsig
+    static __host__ __device__ constexpr int small_floats(int V) {
+        return 8 * DK + 4 * DK + 4 * NP + NT * NP + 2 * V * NP + 8;
+    }
+    static __host__ __device__ constexpr int lds_bytes(int V) { return R_BYTES + K_BYTES + 4 * small_floats(V); }
+};
+
+__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of this lane's half
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned int pack_h2(float a, float b) {
+    _Float16 x = (_Float16)a, y = (_Float16)b;
+    return (unsigned int)__builtin_bit_cast(unsigned short, x) | ((unsigned int)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float h2_lo(unsigned int u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffff)); }
+__device__ __forceinline__ float h2_hi(unsigned int u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+
+template <typename IOT> __device__ __forceinline__ bf16x8 load8_bf16(const IOT *p);
+template <> __device__ __forceinline__ bf16x8 load8_bf16<unsigned short>(const unsigned short *p) {
+    return *(const bf16x8 *)p;
+}
+template <> __device__ __forceinline__ bf16x8 load8_bf16<float>(const float *p) {
+    const float4 a = *(const float4 *)p, b = *(const float4 *)(p + 4);
+    bf16x8 r;
+    r[0] = f2bf(a.x); r[1] = f2bf(a.y); r[2] = f2bf(a.z); r[3] = f2bf(a.w);
+    r[4] = f2bf(b.x); r[5] = f2bf(b.y); r[6] = f2bf(b.z); r[7] = f2bf(b.w);
+    return r;
+}
+template <typename IOT> __device__ __forceinline__ void store4(IOT *p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float *p, float a, float b, float c, float d) {
+    *(float4 *)p = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<unsigned short>(unsigned short *p, float a, float b, float c, float d) {
+    *(uint2 *)p = make_uint2(pack_bf16(a, b), pack_bf16(c, d));
+}
+
+// B-operand fragments (k order of the accumulator) of an X-layout slab
+template <int NT>
+__device__ __forceinline__ void pack_slab(bf16x8 (&Xp)[NT][2], const f32x16 (&X)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Xp[t][s][j] = (short)f2bf(X[t][8 * s + j]);
+}
+
+template <int NT, int DK, typename IOT>
+__global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs a) {
+    using Cfg = FusedCfg<NT, DK>;
+    constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = Cfg::LDK, KS = Cfg::KS, DT = Cfg::DT, DP = Cfg::DP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short *AT = (unsigned short *)smem;                   // [NP][LDA]   A_m^T, k-permuted columns
+    unsigned short *VT0 = AT;                                      // [DP][LDA]   (aliases AT after the chains)
+    unsigned short *VTL = AT + DP * LDA;                           // [DP][LDA]
+    unsigned short *bT = AT + 2 * DP * LDA;                        // [4][NP][BTS]
+    unsigned short *Ksm = (unsigned short *)(smem + Cfg::R_BYTES); // [NP][LDK]
+    float *fs = (float *)(smem + Cfg::R_BYTES + Cfg::K_BYTES);
+    float *sqk = fs, *qbar = sqk + 8 * DK, *kbar = qbar + DK, *vs0 = kbar + DK, *vsL = vs0 + DK;
+    float *rCr = vsL + DK, *rCl = rCr + NP, *cCr = rCl + NP, *cCl = cCr + NP;
+    float *colpart = cCl + NP;                                     // [NT][NP]
+    float *rS = colpart + NT * NP, *cS = rS + a.V * NP;            // [V][NP]
+    float *wsig = cS + a.V * NP;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int N = a.N, V = a.V, H = a.H, R = a.r;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H;
+    const int qi = 32 * w + r;                 // this lane's query
+    const bool qok = qi < N;
+    const float invN = 1.f / (float)N;
+
+    // ---------------- P0: stage K, q fragments, scales ----------------
+    {
+        const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh;
+        constexpr int CH = DK / 8;
+        for (int c = tid; c < NP * CH; c += NT * 64) {
+            const int j = c / CH, dc = c % CH;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (j < N) v = load8_bf16<IOT>(kp + (int64_t)j * a.k.sn + dc * 8);
+            *(bf16x8 *)&Ksm[j * LDK + dc * 8] = v;
+        }
+        for (int c = tid; c < V * DK; c += NT * 64) sqk[c] = a.sqk[((c / DK) * H + hh) * DK + (c % DK)];
+        for (int c = tid; c < DK; c += NT * 64) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
+        if (tid == 0) wsig[0] = 1.f / (1.f + __expf(-*a.chain_logit));
+    }
+    {
+    bf16x8 qf[KS];
+    {
+        const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qok) v = load8_bf16<IOT>(qp + 16 * s + 8 * h);
+            qf[s] = v;
+        }
+    }
+    // per-wave partial of qbar (sum over this wave's queries); colpart doubles as [NT][DK] scratch here
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = half_sum32(bf2f((unsigned short)qf[s][j]));
+            if (r == 0) colpart[w * DK + 16 * s + 8 * h + j] = t;
+        }
+    __syncthreads();
+    if (tid < DK) {
+        float sk = 0.f, sq = 0.f;
+        for (int j = 0; j < N; ++j) sk += bf2f(Ksm[j * LDK + tid]);
+        for (int ww = 0; ww < NT; ++ww) sq += colpart[ww * DK + tid];
+        kbar[tid] = sk * invN; qbar[tid] = sq * invN;
+    }
+    __syncthreads();
+    // row / col means of S_v are linear in q, k:  rS_v[i] = Qe_v[i,:].kbar ; cS_v[j] = k[j,:].(sqk_v*qbar)
+    for (int v = 0; v < V; ++v) {
+        float p = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 16 * s + 8 * h + j;
+                p = fmaf(bf2f((unsigned short)qf[s][j]) * sqk[v * DK + d], kbar[d], p);
+            }
+        p += __shfl_xor(p, 32, 64);
+        if (h == 0) rS[v * NP + qi] = p;
+        if (tid < NP) {
+            float c = 0.f;
+            for (int d = 0; d < DK; ++d) c = fmaf(bf2f(Ksm[tid * LDK + d]) * sqk[v * DK + d], qbar[d], c);
+            cS[v * NP + tid] = c;
+        }
+    }
+    }
+
+    // ---------------- helpers ----------------
+    const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
+    auto make_qe = [&](bf16x8 (&qe)[KS], int v) {   // Qe_v fragments; q re-read from L2 (keeps 16 VGPRs free)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qok) qv = load8_bf16<IOT>(qrow + 16 * s + 8 * h);
+            const float4 s0 = *(const float4 *)&sqk[v * DK + 16 * s + 8 * h];
+            const float4 s1 = *(const float4 *)&sqk[v * DK + 16 * s + 8 * h + 4];
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qe[s][j] = (short)f2bf(bf2f((unsigned short)qv[j]) * sc[j]);
+        }
+    };
+    auto s_tile = [&](const bf16x8 (&qe)[KS], int t) -> f32x16 {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 af = *(const bf16x8 *)&Ksm[(32 * t + r) * LDK + 16 * s + 8 * h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qe[s], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // A_v^T slab = softmax over keys (registers) of S_v^T            :500-507
+    auto a_slab = [&](f32x16 (&X)[NT], int v) {
+        bf16x8 qe[KS];
+        make_qe(qe, v);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            X[t] = s_tile(qe, t);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                if (32 * t + tile_row(g, h) >= N) X[t][g] = -INFINITY;
+                mx = fmaxf(mx, X[t][g]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sm = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { const float e = __expf(X[t][g] - mx); X[t][g] = e; sm += e; }
+        sm += __shfl_xor(sm, 32, 64);
+        const float inv = 1.f / sm;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) X[t] *= inv;
+    };
+    auto store_AT = [&](const f32x16 (&X)[NT]) {   // AT[j][perm(i)] = X^T slab
+        const int col = 32 * w + 16 * (r >> 4) + kperm16(r & 15);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) AT[(32 * t + tile_row(g, h)) * LDA + col] = f2bf(X[t][g]);
+    };
+    auto chain_gemm = [&](f32x16 (&Xn)[NT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
+#pragma unroll
+        for (int to = 0; to < NT; ++to) {
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * to + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
+                }
+            Xn[to] = acc;
+        }
+    };
+    // chain product over views order[0..V-1] (transposed): X <- A_{o[V-1]}^T .. A_{o[1]}^T A_{o[0]}^T[:, I]
+    auto run_chain = [&](f32x16 (&X)[NT], bool forward) {
+        bf16x8 Xp[NT][2];
+        a_slab(X, forward ? 0 : V - 1);
+        for (int m = 1; m < V; ++m) {
+            pack_slab<NT>(Xp, X);
+            a_slab(X, forward ? m : V - 1 - m);
+            __syncthreads();              // previous step's readers of AT are done
+            store_AT(X);
+            __syncthreads();
+            chain_gemm(X, AT, Xp);
+        }
+    };
+    // X <- log(X + eps) ; row means -> rout[i] ; per-wave column partial sums -> colpart[w][j]
+    // column sums over the 32 lanes of a half: butterfly that halves the live registers each
+    // step (16 shuffles per tile instead of 80); lane r (even) ends with the sum of register r>>1.
+    auto log_means = [&](f32x16 (&X)[NT], float *rout) {
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float c[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float v = __logf(X[t][g] + EPSC);
+                X[t][g] = v;
+                rs += (32 * t + tile_row(g, h) < N) ? v : 0.f;
+                c[g] = qok ? v : 0.f;
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {          // xor 16, 8, 4, 2
+                const int n = 8 >> st;                 // registers kept after this step
+                const bool up = (r >> (4 - st)) & 1;
+#pragma unroll
+                for (int k = 0; k < n; ++k) {
+                    const float keep = up ? c[k + n] : c[k];
+                    const float send = up ? c[k] : c[k + n];
+                    c[k] = keep + __shfl_xor(send, 16 >> st, 64);
+                }
+            }
+            c[0] += __shfl_xor(c[0], 1, 64);
+            if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        if (h == 0) rout[qi] = rs * invN;
+    };
+
+    f32x16 X[NT];
+    // ---------------- chain <- : only its log-means survive           :513-515, :521
+    run_chain(X, false);
+    log_means(X, rCl);
+    __syncthreads();
+    if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
+    // ---------------- chain -> : C->^T stays in X                      :508-512, :520
+    run_chain(X, true);
+    __syncthreads();                      // AT free: build V0^T, VL^T (k-permuted key columns)
+    {
+        const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
+        const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
+        constexpr int CH = DK / 8;
+        for (int c = tid; c < NP * CH; c += NT * 64) {
+            const int j = c / CH, dc = c % CH;
+            bf16x8 x0 = {0, 0, 0, 0, 0, 0, 0, 0}, xL = x0;
+            if (j < N) { x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8); xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8); }
+            const int col = (j & ~15) + kperm16(j & 15);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = dc * 8 + e;
+                VT0[d * LDA + col] = f2bf(bf2f((unsigned short)x0[e]) * vs0[d]);
+                VTL[d * LDA + col] = f2bf(bf2f((unsigned short)xL[e]) * vsL[d]);
+            }
+        }
+        if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NT * 64) { VT0[DK * LDA + c] = 0; VTL[DK * LDA + c] = 0; }
+    }
+    IOT *yp = (IOT *)a.y.ptr + b * a.y.sb + hh * a.y.sh + (int64_t)qi * a.y.sn;
+    float *ych = (float *)a.saved + (size_t)blockIdx.x * N * DK;   // saved: w * y_chain (BH,N,dk) fp32
+    {
+        bf16x8 Xp[NT][2];
+        pack_slab<NT>(Xp, X);
+        log_means(X, rCr);                // X = Cr
+        __syncthreads();                  // VT*, colpart complete
+        if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
+        const float wv = wsig[0];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {  // y_chain^T = VL^T C->^T       :556-560 (as C-> vL); parked in y
+            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 af = *(const bf16x8 *)&VTL[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
+                }
+            if (qok) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = 32 * dt + 8 * g4 + 4 * h;
+                    if (d0 < DK) *(float4 *)&ych[(size_t)qi * DK + d0] = make_float4(wv * acc[4 * g4], wv * acc[4 * g4 + 1], wv * acc[4 * g4 + 2], wv * acc[4 * g4 + 3]);
+                }
+            }
+        }
+    }
+    unsigned int crp[NT][8];              // Cr (later Smix) as packed fp16
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(X[t][2 * p], X[t][2 * p + 1]);
+    __syncthreads();                      // cCr visible
+    // ---------------- gate vectors                                     :323-326
+    const int C = 2 * V + 2;
+    if (tid < NP) {                       // b[g,k,j] -> bT[g][j][slots] = [b_hi | b_hi | b_lo | 0]
+        const int j = tid;
+        for (int g = 0; g < 4; ++g) {
+            unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+            if (j < N)
+                for (int k = 0; k < R; ++k) {
+                    const int o = g * R + k;
+                    float s = a.bc[o];
+                    for (int c = 0; c < C; ++c) {
+                        const float f = c < V ? cS[c * NP + j] : (c < 2 * V ? rS[(c - V) * NP + j] : (c == 2 * V ? cCr[j] : cCl[j]));
+                        s = fmaf(a.Wc[o * C + c], f, s);
+                    }
+                    hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
+                }
+            unsigned short *row = bT + (g * NP + j) * BTS;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0; }
+        }
+    }
+    bf16x8 af4[4];                        // a[g,k,i] as B fragments: slots [a_hi | a_lo | a_hi | 0]
+    for (int g = 0; g < 4; ++g) {
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < R; ++k) {
+            const int o = g * R + k;
+            float s = a.br[o];
+            for (int c = 0; c < C; ++c) {
+                const float f = c < V ? rS[c * NP + qi] : (c < 2 * V ? cS[(c - V) * NP + qi] : (c == 2 * V ? rCr[qi] : rCl[qi]));
+                s = fmaf(a.Wr[o * C + c], f, s);
+            }
+            av[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned short hi = f2bf(av[k]), lo = f2bf(av[k] - bf2f(hi));
+            af4[g][k] = (short)hi;                          // h=0: slots 0-3 a_hi ; h=1: slots 8-11 a_hi
+            af4[g][4 + k] = h == 0 ? (short)lo : (short)0;  // h=0: slots 4-7 a_lo ; h=1: slots 12-15 0
+        }
+    }
+    __syncthreads();                      // bT complete
+    // ---------------- score-space mix, tile by tile                    :537-547
+    const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
+    float mxrow = -INFINITY;
+    auto gate_tile = [&](int t, int g4) -> f32x16 {        // sigmoid(a_g^T b_g) for one 32x32 tile
+        const f32x16 z0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8 bfrag = *(const bf16x8 *)&bT[(g4 * NP + 32 * t + r) * BTS + 8 * h];
+        f32x16 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, af4[g4], z0, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) z[g] = 1.f / (1.f + __expf(-z[g]));
+        return z;
+    };
+    // runtime loop over key tiles (an unrolled one makes hipcc overlap the tiles' live ranges and
+    // spill ~1000 VGPRs); the per-tile packed Cr/Smix registers are selected with a uniform switch.
+#pragma nounroll
+    for (int t = 0; t < NT; ++t) {
+        unsigned int cw[8];
+        switch (t) {
+#define MOPK_CASE(T_) case T_: if (T_ < NT) { _Pragma("unroll") for (int p = 0; p < 8; ++p) cw[p] = crp[T_ < NT ? T_ : 0][p]; } break;
+            MOPK_CASE(0) MOPK_CASE(1) MOPK_CASE(2) MOPK_CASE(3) MOPK_CASE(4) MOPK_CASE(5) MOPK_CASE(6)
+#undef MOPK_CASE
+            default: break;
+        }
+        f32x16 S0, O, L;
+        {
+            bf16x8 qe[KS];
+            make_qe(qe, 0);
+            S0 = s_tile(qe, t);
+            f32x16 mx = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, se;
+            O = mx;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) se[g] = 1.f;
+            for (int v = 1; v < V; ++v) {     // online logsumexp over views, relative to S_0
+                make_qe(qe, v);
+                const f32x16 Sv = s_tile(qe, t);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    O[g] += Sv[g];
+                    const float d = Sv[g] - S0[g];
+                    const float e = __expf(-fabsf(d - mx[g]));
+                    se[g] = d > mx[g] ? fmaf(se[g], e, 1.f) : se[g] + e;
+                    mx[g] = fmaxf(mx[g], d);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) L[g] = mx[g] + __logf(se[g]);   // lse_v S_v - S_0
+        }
+        // Smix = S0 + (G_and - nb G_not) O + G_or L + G_chain Cr, one gate at a time
+        {
+            const f32x16 G = gate_tile(t, 0);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) S0[g] = fmaf(G[g], O[g], S0[g]);
+        }
+        {
+            const f32x16 G = gate_tile(t, 1);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) S0[g] = fmaf(G[g], L[g], S0[g]);
+        }
+        {
+            const f32x16 G = gate_tile(t, 2);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) S0[g] = fmaf(-nb * G[g], O[g], S0[g]);
+        }
+        {
+            const f32x16 G = gate_tile(t, 3);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float s0 = fmaf(G[2 * p], h2_lo(cw[p]), S0[2 * p]);
+                float s1 = fmaf(G[2 * p + 1], h2_hi(cw[p]), S0[2 * p + 1]);
+                if (32 * t + tile_row(2 * p, h) >= N) s0 = -INFINITY;
+                if (32 * t + tile_row(2 * p + 1, h) >= N) s1 = -INFINITY;
+                mxrow = fmaxf(mxrow, fmaxf(s0, s1));
+                cw[p] = pack_h2(s0, s1);
+            }
+        }
+        switch (t) {
+#define MOPK_CASE(T_) case T_: if (T_ < NT) { _Pragma("unroll") for (int p = 0; p < 8; ++p) crp[T_ < NT ? T_ : 0][p] = cw[p]; } break;
+            MOPK_CASE(0) MOPK_CASE(1) MOPK_CASE(2) MOPK_CASE(3) MOPK_CASE(4) MOPK_CASE(5) MOPK_CASE(6)
+#undef MOPK_CASE
+            default: break;
+        }
+    }
+    // ---------------- softmax over keys + P V0                         :551-554
+    mxrow = fmaxf(mxrow, __shfl_xor(mxrow, 32, 64));
+    float l = 0.f;
+    bf16x8 Pp[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const float e0 = __expf(h2_lo(crp[t][p]) - mxrow), e1 = __expf(h2_hi(crp[t][p]) - mxrow);
+            l += e0 + e1;
+            Pp[t][p >> 2][2 * (p & 3)] = (short)f2bf(e0);
+            Pp[t][p >> 2][2 * (p & 3) + 1] = (short)f2bf(e1);
+        }
+    l += __shfl_xor(l, 32, 64);
+    const float invl = 1.f / l;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 af = *(const bf16x8 *)&VT0[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Pp[t][s], acc, 0, 0, 0);
+            }
+        if (qok) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int d0 = 32 * dt + 8 * g4 + 4 * h;
+                if (d0 < DK) {
+                    const float4 yc = *(const float4 *)&ych[(size_t)qi * DK + d0];      // w * y_chain (own earlier store)
+                    store4<IOT>(yp + d0, fmaf(acc[4 * g4], invl, yc.x), fmaf(acc[4 * g4 + 1], invl, yc.y),
+                                fmaf(acc[4 * g4 + 2], invl, yc.z), fmaf(acc[4 * g4 + 3], invl, yc.w));
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static int pick_nt(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
+
+template <int NT, int DK>
+static int launch_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
+    const int lds = FusedCfg<NT, DK>::lds_bytes(a->V);
+    if (lds > 160 * 1024) return MOPK_ERR_UNSUPPORTED;
+    const dim3 grid(a->B * a->H), block(NT * 64);
+    if (a->io_dtype == MOPK_BF16) {
+        auto kfn = ew_fused_fwd_kernel<NT, DK, unsigned short>;
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a);
+    } else {
+        auto kfn = ew_fused_fwd_kernel<NT, DK, float>;
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a);
+    }
+    MOPK_CHECK_LAUNCH();
+    return MOPK_OK;
+}
+
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
+    if (a->precision != MOPK_PREC_BF16) return 0;             // fused kernels are the bf16-MFMA path
+    if (a->q.sv != 0 || a->k.sv != 0) return 0;               // share_qkv only (per-view K restaging not built)
+    if (pick_nt(a->N) == 0) return 0;
+    if (a->dk != 16 && a->dk != 32 && a->dk != 64) return 0;
+    if (a->V < 2 || a->V > 8 || a->r < 1 || a->r > 4) return 0;
+    const int es = a->io_dtype == MOPK_BF16 ? 2 : 4;
+    const int64_t al = 16 / es;                               // vector loads: 8 (bf16) / 4 (fp32) element alignment
+    const MopkView4 vs[3] = {a->v0, a->vL, a->y};
+    for (const auto &v : vs) if (!aligned16(v.ptr) || v.sb % al || v.sh % al || v.sn % al) return 0;
+    if (!aligned16(a->q.ptr) || a->q.sb % al || a->q.sh % al || a->q.sn % al) return 0;
+    if (!aligned16(a->k.ptr) || a->k.sb % al || a->k.sh % al || a->k.sn % al) return 0;
+    return 1;
+}
+
+int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
+    if (!ew_fused_fwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
+    const int nt = pick_nt(a->N);
+#define MOPK_DK(NT_)                                                  \
+    switch (a->dk) {                                                  \
+        case 16: return launch_fwd<NT_, 16>(a, st);                   \
+        case 32: return launch_fwd<NT_, 32>(a, st);                   \
+        default: return launch_fwd<NT_, 64>(a, st);                   \
+    }
+    switch (nt) {
+        case 1: MOPK_DK(1)
+        case 2: MOPK_DK(2)
+        case 4: MOPK_DK(4)
+        default: MOPK_DK(7)
+    }
+    return MOPK_ERR_UNSUPPORTED;
+#undef MOPK_DK
+}
+
+}  // namespace mopk

@@ -72,6 +72,7 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 # ---- optional kernel timing (bench.py): HIP events on the stream the kernels are launched on ----
+LAST_PATH = {}  # entry point -> MopkPath actually requested on the last call (tests assert on it)
 _TIMING = None  # dict name -> list[(start_event, stop_event)] when enabled
 
 
@@ -132,7 +133,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
     """y = EdgewiseMSA core(qkv, ...) ; reference attention_variants.py:500-562."""
 
     @staticmethod
-    def forward(ctx, qkv, sqk, vs0, vsL, Wr, br, Wc, bc, logit, beta_not, V, prec, path):
+    def forward(ctx, qkv, sqk, vs0, vsL, Wr, br, Wc, bc, logit, beta_not, V, prec, path, want_bwd):
         _require_gpu(qkv, "EdgewiseMSA")
         lib = L.lib()
         B, N, Vq, _, H, dk = qkv.shape
@@ -151,6 +152,9 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.chain_logit = f["logit"].data_ptr()
         y = torch.empty(B, N, H, dk, dtype=qkv.dtype, device=dev)
         a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
+        if path == L.PATH_AUTO and not want_bwd and lib.mopk_edgewise_fused_supported(C.byref(a)):
+            a.path = path = L.PATH_FUSED  # forward-only: fused kernel (the fused backward is not built yet)
+        LAST_PATH["edgewise_fwd"] = path
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
@@ -202,15 +206,17 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
             rc = lib.mopk_edgewise_lowrank_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_lowrank_bwd")
         return (dqkv, dsqk.sum(0), dvs0.sum(0), dvsL.sum(0), dWr, dbr, dWc, dbc,
-                dlg.sum().reshape(()), None, None, None, None)
+                dlg.sum().reshape(()), None, None, None, None, None)
 
 
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,
                           n_views: int, precision: Optional[int] = None, path: Optional[int] = None):
     """qkv: (B,N,Vq,3,H,dk) with Vq in {1 (share_qkv), n_views}; returns (B,N,H*dk)."""
     prec = _prec_for(qkv.dtype) if precision is None else precision
+    want_bwd = torch.is_grad_enabled() and any(
+        t.requires_grad for t in (qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit))
     return _EdgewiseLowrankFn.apply(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not,
-                                    n_views, prec, _PATH if path is None else path)
+                                    n_views, prec, _PATH if path is None else path, want_bwd)
 
 
 def sdpa_core(qkv, attn_mask=None):

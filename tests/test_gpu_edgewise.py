@@ -110,3 +110,27 @@ def test_deterministic_bitwise():
     assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1])
     for k in r1[2]:
         assert np.array_equal(r1[2][k], r2[2][k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", [n for n in golden_names("ew_") if "unshared" not in n])
+def test_fused_forward_vs_reference_golden(name, dtype):
+    """forward-only (no_grad) takes the fused gfx950 kernel; bf16 MFMA tolerance 1e-2."""
+    import ctypes as C
+    import mop_amd
+    from mop_amd import ops
+    from mop_amd.nn import EdgewiseMSA
+    d, params, gref, meta = load_golden(name)
+    mop_amd.set_precision("bf16")
+    m = module_from_golden(EdgewiseMSA, params, **_ctor(meta)).to(dtype)
+    x = torch.from_numpy(d["x"]).cuda().to(dtype)
+    ops.enable_timing(True)
+    with torch.no_grad():
+        y = m(x)
+    torch.cuda.synchronize()
+    ops.enable_timing(False)
+    from mop_amd import _lib
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED, "fused kernel was not selected"
+    err = max_abs(y.float().cpu().numpy(), d["y"])
+    print(f"{name} {dtype}: fused fwd max-abs err {err:.3e}")
+    assert err <= TOL_BF16, f"fused fwd y max-abs {err:.3e}"
