@@ -8,6 +8,12 @@ int ew_generic_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_generic_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
+size_t sdpa_saved_bytes(const MopkSdpaArgs *a); size_t sdpa_ws_bytes(const MopkSdpaArgs *a);
+int sdpa_fwd(const MopkSdpaArgs *a, hipStream_t st); int sdpa_bwd(const MopkSdpaArgs *a, hipStream_t st);
+size_t dp_saved_bytes(const MopkDualPathArgs *a); size_t dp_ws_bytes(const MopkDualPathArgs *a);
+int dp_fwd(const MopkDualPathArgs *a, hipStream_t st); int dp_bwd(const MopkDualPathArgs *a, hipStream_t st);
+size_t qt_saved_bytes(const MopkQuartetArgs *a); size_t qt_ws_bytes(const MopkQuartetArgs *a);
+int qt_fwd(const MopkQuartetArgs *a, hipStream_t st); int qt_bwd(const MopkQuartetArgs *a, hipStream_t st);
 
 static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
     if (!a) return MOPK_ERR_BAD_ARG;
@@ -75,18 +81,66 @@ int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream) {
     return ew_generic_bwd(a, (hipStream_t)stream);
 }
 
-// ---- not yet implemented cores: report UNSUPPORTED (callers fail loudly) ----
-size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *) { return 0; }
-size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *) { return 0; }
-int mopk_dualpath_fwd(const MopkDualPathArgs *, void *) { return MOPK_ERR_UNSUPPORTED; }
-int mopk_dualpath_bwd(const MopkDualPathArgs *, void *) { return MOPK_ERR_UNSUPPORTED; }
-size_t mopk_quartet_saved_bytes(const MopkQuartetArgs *) { return 0; }
-size_t mopk_quartet_workspace_bytes(const MopkQuartetArgs *) { return 0; }
-int mopk_quartet_fwd(const MopkQuartetArgs *, void *) { return MOPK_ERR_UNSUPPORTED; }
-int mopk_quartet_bwd(const MopkQuartetArgs *, void *) { return MOPK_ERR_UNSUPPORTED; }
-size_t mopk_sdpa_saved_bytes(const MopkSdpaArgs *) { return 0; }
-size_t mopk_sdpa_workspace_bytes(const MopkSdpaArgs *) { return 0; }
-int mopk_sdpa_fwd(const MopkSdpaArgs *, void *) { return MOPK_ERR_UNSUPPORTED; }
-int mopk_sdpa_bwd(const MopkSdpaArgs *, void *) { return MOPK_ERR_UNSUPPORTED; }
+// ---- sibling cores (generic multi-kernel paths, attn_generic.hip) ----
+static bool v4ok(const MopkView4 &v) { return v.ptr != nullptr; }
+static int base_ok(int B, int H, int N, int dk, int io, int prec) {
+    if (B <= 0 || H <= 0 || N <= 0 || dk <= 0) return MOPK_ERR_BAD_SHAPE;
+    if ((io != MOPK_F32 && io != MOPK_BF16) || (prec != MOPK_PREC_FP32 && prec != MOPK_PREC_BF16)) return MOPK_ERR_BAD_ARG;
+    return MOPK_OK;
+}
+size_t mopk_sdpa_saved_bytes(const MopkSdpaArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0) ? sdpa_saved_bytes(a) : 0; }
+size_t mopk_sdpa_workspace_bytes(const MopkSdpaArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0) ? sdpa_ws_bytes(a) : 0; }
+int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream) {
+    if (!a) return MOPK_ERR_BAD_ARG;
+    int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
+    if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    return sdpa_fwd(a, (hipStream_t)stream);
+}
+int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream) {
+    if (!a) return MOPK_ERR_BAD_ARG;
+    int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
+    if (!v4ok(a->q) || !v4ok(a->dy) || !v4ok(a->dq) || !v4ok(a->dk_) || !v4ok(a->dv) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    return sdpa_bwd(a, (hipStream_t)stream);
+}
+size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2) ? dp_saved_bytes(a) : 0; }
+size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2) ? dp_ws_bytes(a) : 0; }
+int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream) {
+    if (!a) return MOPK_ERR_BAD_ARG;
+    int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
+    if (a->hops < 2) return MOPK_ERR_BAD_SHAPE;
+    if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->v2) || !v4ok(a->y) ||
+        !a->chain_logit || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    return dp_fwd(a, (hipStream_t)stream);
+}
+int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream) {
+    if (!a) return MOPK_ERR_BAD_ARG;
+    int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
+    if (a->hops < 2) return MOPK_ERR_BAD_SHAPE;
+    if (!v4ok(a->dy) || !v4ok(a->dq1) || !v4ok(a->dk1) || !v4ok(a->dv1) || !v4ok(a->dq2) || !v4ok(a->dk2) || !v4ok(a->dv2) ||
+        !a->dlogit_part || !a->chain_logit || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    return dp_bwd(a, (hipStream_t)stream);
+}
+size_t mopk_quartet_saved_bytes(const MopkQuartetArgs *a) { return (a && a->B > 0 && a->H > 0 && a->T > 0 && a->dh > 0) ? qt_saved_bytes(a) : 0; }
+size_t mopk_quartet_workspace_bytes(const MopkQuartetArgs *a) { return (a && a->B > 0 && a->H > 0 && a->T > 0 && a->dh > 0) ? qt_ws_bytes(a) : 0; }
+int mopk_quartet_fwd(const MopkQuartetArgs *a, void *stream) {
+    if (!a) return MOPK_ERR_BAD_ARG;
+    int rc = base_ok(a->B, a->H, a->T, a->dh, a->io_dtype, a->precision); if (rc) return rc;
+    if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->use_quartet && (!v4ok(a->q2) || !v4ok(a->k2) || !a->mixture || !a->quartet_scale)) return MOPK_ERR_BAD_ARG;
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    return qt_fwd(a, (hipStream_t)stream);
+}
+int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream) {
+    if (!a) return MOPK_ERR_BAD_ARG;
+    int rc = base_ok(a->B, a->H, a->T, a->dh, a->io_dtype, a->precision); if (rc) return rc;
+    if (!v4ok(a->dy) || !v4ok(a->dq) || !v4ok(a->dk_) || !v4ok(a->dv) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->use_quartet && (!v4ok(a->dq2) || !v4ok(a->dk2) || !a->dmixture_part || !a->dqscale_part || !a->mixture || !a->quartet_scale)) return MOPK_ERR_BAD_ARG;
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    return qt_bwd(a, (hipStream_t)stream);
+}
 
 }  // extern "C"

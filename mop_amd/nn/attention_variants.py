@@ -181,7 +181,7 @@ class BaselineMSA(nn.Module):
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, N, D = x.shape
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
-        y = ops.sdpa_core(qkv, attn_mask)
+        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], attn_mask)
         return self.proj_drop(self.proj(y))
 
 
@@ -208,7 +208,8 @@ class MultiHopMSA(nn.Module):
         qkv1 = self.qkv1(x).view(B, N, 3, self.h, self.dk)
         qkv2 = self.qkv2(x).view(B, N, 3, self.h, self.dk)
         g = self.gates
-        y = ops.dualpath_core(qkv1, qkv2, self.chain_value_logit, g.get("and_", 1.0), g.get("or_", 0.0),
+        y = ops.dualpath_core(qkv1[:, :, 0], qkv1[:, :, 1], qkv1[:, :, 2], qkv2[:, :, 0], qkv2[:, :, 1], qkv2[:, :, 2],
+                              self.chain_value_logit, g.get("and_", 1.0), g.get("or_", 0.0),
                               g.get("not_", 0.0), g.get("chain", 0.0), self.beta_not, self.hops, attn_mask)
         return self.proj_drop(self.proj(y))
 

@@ -219,9 +219,239 @@ def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_
                                     n_views, prec, _PATH if path is None else path, want_bwd)
 
 
-def sdpa_core(qkv, attn_mask=None):
-    raise NotImplementedError("mopk_sdpa_* kernels are not built yet")
+# --------------------------------------------------------------------------------------
+# sibling cores: plain SDPA, dual-path (MultiHopMSA), Quartet
+# --------------------------------------------------------------------------------------
+def _v4(t: torch.Tensor) -> L.View4:
+    """t: (B,N,H,dk) view with unit inner stride -> MopkView4 (strides b,h,n in elements)."""
+    assert t.dim() == 4 and t.stride(3) == 1, "inner (head_dim) stride must be 1"
+    return L.View4(t.data_ptr(), t.stride(0), t.stride(2), t.stride(1))
 
 
-def dualpath_core(qkv1, qkv2, chain_logit, g_and, g_or, g_not, g_chain, beta_not, hops, attn_mask=None):
-    raise NotImplementedError("mopk_dualpath_* kernels are not built yet")
+def _heads_view(t: torch.Tensor) -> torch.Tensor:
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _mask_u8(attn_mask, B, H, N, dev):
+    """reference convention: broadcastable to (B,H,N,N), 0 = blocked (attention_variants.py:43-44)."""
+    if attn_mask is None:
+        return None, (0, 0, 0)
+    m = (attn_mask.to(dev) != 0).to(torch.uint8)
+    while m.dim() < 4:
+        m = m.unsqueeze(0)
+    m = m.contiguous().expand(B, H, N, N)
+    assert m.stride(3) == 1 or N == 1
+    return m, (m.stride(0), m.stride(1), m.stride(2))
+
+
+def _bias_f32(bias, B, H, N, dev):
+    if bias is None:
+        return None, (0, 0, 0)
+    b = bias.to(dev, torch.float32)
+    while b.dim() < 4:
+        b = b.unsqueeze(0)
+    b = b.contiguous().expand(B, H, N, N)
+    return b, (b.stride(0), b.stride(1), b.stride(2))
+
+
+class _SdpaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, bias, causal, prec):
+        _require_gpu(q, "SDPA")
+        lib = L.lib()
+        q, k, v = _heads_view(q), _heads_view(k), _heads_view(v)
+        B, N, H, dk = q.shape
+        dev = q.device
+        a = L.SdpaArgs()
+        a.B, a.H, a.N, a.dk = B, H, N, dk
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(q), prec, L.PATH_GENERIC, int(bool(causal))
+        a.q, a.k, a.v = _v4(q), _v4(k), _v4(v)
+        m8, ms = _mask_u8(mask, B, H, N, dev)
+        bf, bs = _bias_f32(bias, B, H, N, dev)
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        a.bias, (a.bias_sb, a.bias_sh, a.bias_si) = _ptr(bf), bs
+        y = torch.empty(B, N, H, dk, dtype=q.dtype, device=dev)
+        a.y = _v4(y)
+        saved = _bytes(lib.mopk_sdpa_saved_bytes(C.byref(a)), dev)
+        ws = _bytes(lib.mopk_sdpa_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("sdpa_fwd"):
+            rc = lib.mopk_sdpa_fwd(C.byref(a), _stream())
+        L.check(rc, "mopk_sdpa_fwd")
+        ctx.save_for_backward(q, k, v, saved)
+        ctx.meta = (causal, prec, m8, ms, bf, bs)
+        return y.view(B, N, H * dk)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        q, k, v, saved = ctx.saved_tensors
+        causal, prec, m8, ms, bf, bs = ctx.meta
+        B, N, H, dk = q.shape
+        dev = q.device
+        dy = dy.contiguous().to(q.dtype).view(B, N, H, dk)
+        a = L.SdpaArgs()
+        a.B, a.H, a.N, a.dk = B, H, N, dk
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(q), prec, L.PATH_GENERIC, int(bool(causal))
+        a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(dy), _v4(dy)
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        a.bias, (a.bias_sb, a.bias_sh, a.bias_si) = _ptr(bf), bs
+        dq, dk_, dv = (torch.empty(B, N, H, dk, dtype=q.dtype, device=dev) for _ in range(3))
+        a.dq, a.dk_, a.dv = _v4(dq), _v4(dk_), _v4(dv)
+        ws = _bytes(lib.mopk_sdpa_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("sdpa_bwd"):
+            rc = lib.mopk_sdpa_bwd(C.byref(a), _stream())
+        L.check(rc, "mopk_sdpa_bwd")
+        return dq, dk_, dv, None, None, None, None
+
+
+def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False):
+    """q,k,v: (B,N,H,dk) views. Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive."""
+    return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype))
+
+
+class _DualPathFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q1, k1, v1, q2, k2, v2, logit, gates, beta_not, hops, mask, causal, prec):
+        _require_gpu(q1, "MultiHopMSA")
+        lib = L.lib()
+        ts = [_heads_view(t) for t in (q1, k1, v1, q2, k2, v2)]
+        B, N, H, dk = ts[0].shape
+        dev = ts[0].device
+        lg = _f32c(logit).reshape(1)
+        a = L.DualPathArgs()
+        a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, L.PATH_GENERIC, int(bool(causal))
+        a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
+        a.beta_not = float(beta_not)
+        a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
+        m8, ms = _mask_u8(mask, B, H, N, dev)
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        a.chain_logit = lg.data_ptr()
+        y = torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev)
+        a.y = _v4(y)
+        saved = _bytes(lib.mopk_dualpath_saved_bytes(C.byref(a)), dev)
+        ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("dualpath_fwd"):
+            rc = lib.mopk_dualpath_fwd(C.byref(a), _stream())
+        L.check(rc, "mopk_dualpath_fwd")
+        ctx.save_for_backward(*ts, lg, saved)
+        ctx.meta = (gates, beta_not, hops, causal, prec, m8, ms)
+        return y.view(B, N, H * dk)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        *ts, lg, saved = ctx.saved_tensors
+        gates, beta_not, hops, causal, prec, m8, ms = ctx.meta
+        B, N, H, dk = ts[0].shape
+        dev = ts[0].device
+        dy = dy.contiguous().to(ts[0].dtype).view(B, N, H, dk)
+        a = L.DualPathArgs()
+        a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, L.PATH_GENERIC, int(bool(causal))
+        a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
+        a.beta_not = float(beta_not)
+        a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        a.chain_logit = lg.data_ptr()
+        a.y, a.dy = _v4(dy), _v4(dy)
+        gs = [torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(6)]
+        a.dq1, a.dk1, a.dv1, a.dq2, a.dk2, a.dv2 = (_v4(g) for g in gs)
+        dlg = torch.empty(B, H, dtype=torch.float32, device=dev)
+        a.dlogit_part = dlg.data_ptr()
+        ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("dualpath_bwd"):
+            rc = lib.mopk_dualpath_bwd(C.byref(a), _stream())
+        L.check(rc, "mopk_dualpath_bwd")
+        return (*gs, dlg.sum().reshape(()), None, None, None, None, None, None)
+
+
+def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_chain, beta_not, hops,
+                  attn_mask=None, causal=False):
+    return _DualPathFn.apply(q1, k1, v1, q2, k2, v2, chain_logit, (g_and, g_or, g_not, g_chain), beta_not,
+                             int(hops), attn_mask, causal, _prec_for(q1.dtype))
+
+
+class _QuartetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, q2, k2, mixture, qscale, add_mask, eps, use_quartet, need_weights, prec):
+        _require_gpu(q, "CausalSelfAttention")
+        lib = L.lib()
+        ts = [_heads_view(t) for t in ((q, k, v, q2, k2) if use_quartet else (q, k, v))]
+        B, T, H, dh = ts[0].shape
+        dev = ts[0].device
+        a = L.QuartetArgs()
+        a.B, a.H, a.T, a.dh = B, H, T, dh
+        a.io_dtype, a.precision, a.path = _io_dtype(ts[0]), prec, L.PATH_GENERIC
+        a.use_quartet, a.eps = int(bool(use_quartet)), float(eps)
+        a.q, a.k, a.v = _v4(ts[0]), _v4(ts[1]), _v4(ts[2])
+        sc = []
+        if use_quartet:
+            a.q2, a.k2 = _v4(ts[3]), _v4(ts[4])
+            sc = [_f32c(mixture).reshape(1), _f32c(qscale).reshape(1)]
+            a.mixture, a.quartet_scale = sc[0].data_ptr(), sc[1].data_ptr()
+        am, ams = _bias_f32(add_mask, B, H, T, dev)
+        a.add_mask, (a.am_sb, a.am_sh, a.am_si) = _ptr(am), ams
+        y = torch.empty(B, T, H, dh, dtype=ts[0].dtype, device=dev)
+        a.y = _v4(y)
+        attn = torch.empty(B, H, T, T, dtype=torch.float32, device=dev) if need_weights else None
+        a.attn = _ptr(attn)
+        saved = _bytes(lib.mopk_quartet_saved_bytes(C.byref(a)), dev)
+        ws = _bytes(lib.mopk_quartet_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("quartet_fwd"):
+            rc = lib.mopk_quartet_fwd(C.byref(a), _stream())
+        L.check(rc, "mopk_quartet_fwd")
+        ctx.save_for_backward(*ts, *sc, saved)
+        ctx.meta = (eps, use_quartet, prec, am, ams)
+        out = y.view(B, T, H * dh)
+        if need_weights:
+            ctx.mark_non_differentiable(attn)
+            return out, attn
+        return out
+
+    @staticmethod
+    def backward(ctx, dy, *unused):
+        lib = L.lib()
+        eps, use_quartet, prec, am, ams = ctx.meta
+        if use_quartet:
+            q, k, v, q2, k2, mix, qs, saved = ctx.saved_tensors
+        else:
+            q, k, v, saved = ctx.saved_tensors
+        B, T, H, dh = q.shape
+        dev = q.device
+        dy = dy.contiguous().to(q.dtype).view(B, T, H, dh)
+        a = L.QuartetArgs()
+        a.B, a.H, a.T, a.dh = B, H, T, dh
+        a.io_dtype, a.precision, a.path = _io_dtype(q), prec, L.PATH_GENERIC
+        a.use_quartet, a.eps = int(bool(use_quartet)), float(eps)
+        a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(dy), _v4(dy)
+        a.add_mask, (a.am_sb, a.am_sh, a.am_si) = _ptr(am), ams
+        n = 5 if use_quartet else 3
+        gs = [torch.empty(B, T, H, dh, dtype=q.dtype, device=dev) for _ in range(n)]
+        a.dq, a.dk_, a.dv = _v4(gs[0]), _v4(gs[1]), _v4(gs[2])
+        dmix = dqs = None
+        if use_quartet:
+            a.q2, a.k2, a.dq2, a.dk2 = _v4(q2), _v4(k2), _v4(gs[3]), _v4(gs[4])
+            a.mixture, a.quartet_scale = mix.data_ptr(), qs.data_ptr()
+            dmix = torch.empty(B, H, dtype=torch.float32, device=dev)
+            dqs = torch.empty(B, H, dtype=torch.float32, device=dev)
+            a.dmixture_part, a.dqscale_part = dmix.data_ptr(), dqs.data_ptr()
+        ws = _bytes(lib.mopk_quartet_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("quartet_bwd"):
+            rc = lib.mopk_quartet_bwd(C.byref(a), _stream())
+        L.check(rc, "mopk_quartet_bwd")
+        if use_quartet:
+            return (gs[0], gs[1], gs[2], gs[3], gs[4], dmix.sum().reshape(1), dqs.sum().reshape(1),
+                    None, None, None, None, None)
+        return (gs[0], gs[1], gs[2], None, None, None, None, None, None, None, None, None)
+
+
+def quartet_core(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights=False):
+    return _QuartetFn.apply(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights,
+                            _prec_for(q.dtype))
