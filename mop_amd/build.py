@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmopk.so")
-SOURCES = ["api.hip", "edgewise_generic.hip", "edgewise_fused.hip", "attn_generic.hip"]
+SOURCES = ["api.hip", "edgewise_generic.hip", "edgewise_fused.hip", "edgewise_fused_bwd.hip", "attn_generic.hip"]
 
 
 def _hipcc() -> str:

@@ -8,6 +8,9 @@ int ew_generic_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_generic_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
+int ew_fused_bwd_supported(const MopkEdgewiseArgs *a);
+size_t ew_fused_bwd_ws_bytes(const MopkEdgewiseArgs *a);
+int ew_fused_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
 size_t sdpa_saved_bytes(const MopkSdpaArgs *a); size_t sdpa_ws_bytes(const MopkSdpaArgs *a);
 int sdpa_fwd(const MopkSdpaArgs *a, hipStream_t st); int sdpa_bwd(const MopkSdpaArgs *a, hipStream_t st);
 size_t dp_saved_bytes(const MopkDualPathArgs *a); size_t dp_ws_bytes(const MopkDualPathArgs *a);
@@ -65,7 +68,7 @@ size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a) {
 }
 size_t mopk_edgewise_workspace_bytes(const MopkEdgewiseArgs *a) {
     if (!a || a->B <= 0 || a->H <= 0 || a->N <= 0 || a->dk <= 0 || a->V < 2 || a->r < 1) return 0;
-    if (a->path == MOPK_PATH_FUSED) return 256;
+    if (a->path == MOPK_PATH_FUSED) return ew_fused_fwd_supported(a) ? ew_fused_bwd_ws_bytes(a) : 0;   // backward scratch (forward needs none)
     return ew_generic_workspace_bytes(a);
 }
 int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {
@@ -77,7 +80,7 @@ int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {
 int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, true);
     if (rc) return rc;
-    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    if (a->path == MOPK_PATH_FUSED) return ew_fused_bwd(a, (hipStream_t)stream);
     return ew_generic_bwd(a, (hipStream_t)stream);
 }
 

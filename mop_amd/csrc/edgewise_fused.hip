@@ -18,71 +18,9 @@
 //     splits of a and b packed into the K=16 slots, i.e. ~fp32-accurate.
 //
 // HBM traffic per (b,h): q,k,v in + y out (~100 KB) for 0.9 GFLOP -> MFMA/VALU bound.
-#include "common.h"
+#include "fused_common.h"
 
 namespace mopk {
-
-constexpr float EPSC = 1e-6f;   // attention_variants.py:516
-constexpr int BTS = 24;         // bT row stride (ushorts): 16 k-slots + 8 pad (48 B, 16-B aligned)
-
-__host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int kperm16(int k) { return (k & 3) | ((k & 4) << 1) | ((k & 8) >> 1); }
-__device__ __forceinline__ int tile_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
-template <int NT, int DK>
-struct FusedCfg {
-    static constexpr int NP = NT * 32, LDA = NP + 8, LDK = DK + 8, KS = DK / 16;
-    static constexpr int DT = DK >= 32 ? DK / 32 : 1, DP = DT * 32;
-    static constexpr int R_BYTES = imax(NP * LDA * 2, 2 * DP * LDA * 2 + 4 * NP * BTS * 2);
-    static constexpr int K_BYTES = NP * LDK * 2;
-    // fp32 scratch (floats): sqk[8][DK] qbar kbar vs0 vsL [DK] | rCr rCl cCr cCl [NP] | colpart[NT][NP] | rS cS [V][NP] | wsig
-    static __host__ __device__ constexpr int small_floats(int V) {
-        return 8 * DK + 4 * DK + 4 * NP + NT * NP + 2 * V * NP + 8;
-    }
-    static __host__ __device__ constexpr int lds_bytes(int V) { return R_BYTES + K_BYTES + 4 * small_floats(V); }
-};
-
-__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes of this lane's half
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned int pack_h2(float a, float b) {
-    _Float16 x = (_Float16)a, y = (_Float16)b;
-    return (unsigned int)__builtin_bit_cast(unsigned short, x) | ((unsigned int)__builtin_bit_cast(unsigned short, y) << 16);
-}
-__device__ __forceinline__ float h2_lo(unsigned int u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffff)); }
-__device__ __forceinline__ float h2_hi(unsigned int u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
-
-template <typename IOT> __device__ __forceinline__ bf16x8 load8_bf16(const IOT *p);
-template <> __device__ __forceinline__ bf16x8 load8_bf16<unsigned short>(const unsigned short *p) {
-    return *(const bf16x8 *)p;
-}
-template <> __device__ __forceinline__ bf16x8 load8_bf16<float>(const float *p) {
-    const float4 a = *(const float4 *)p, b = *(const float4 *)(p + 4);
-    bf16x8 r;
-    r[0] = f2bf(a.x); r[1] = f2bf(a.y); r[2] = f2bf(a.z); r[3] = f2bf(a.w);
-    r[4] = f2bf(b.x); r[5] = f2bf(b.y); r[6] = f2bf(b.z); r[7] = f2bf(b.w);
-    return r;
-}
-template <typename IOT> __device__ __forceinline__ void store4(IOT *p, float a, float b, float c, float d);
-template <> __device__ __forceinline__ void store4<float>(float *p, float a, float b, float c, float d) {
-    *(float4 *)p = make_float4(a, b, c, d);
-}
-template <> __device__ __forceinline__ void store4<unsigned short>(unsigned short *p, float a, float b, float c, float d) {
-    *(uint2 *)p = make_uint2(pack_bf16(a, b), pack_bf16(c, d));
-}
-
-// B-operand fragments (k order of the accumulator) of an X-layout slab
-template <int NT>
-__device__ __forceinline__ void pack_slab(bf16x8 (&Xp)[NT][2], const f32x16 (&X)[NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Xp[t][s][j] = (short)f2bf(X[t][8 * s + j]);
-}
 
 template <int NT, int DK, typename IOT>
 __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs a) {

@@ -1,0 +1,1124 @@
+// EdgewiseMSA low-rank core -- fused gfx950 BACKWARD kernel (bf16 MFMA, fp32 accumulate).
+//
+// One workgroup per (batch, head), NT = ceil(N/32) waves, wave w owns queries I = [32w, 32w+32).
+// The forward is recomputed on-chip (same X-layout chains as edgewise_fused.hip); the only N x N data
+// that touches memory are bf16 images this workgroup writes and re-reads itself (L2 / Infinity Cache):
+//   * T_m^T, U_m^T prefix products in "AT format" (rows = keys, k-permuted query columns): the B operand
+//     of dA_m = T_{m-1}^T D_m, whose contraction runs over queries (= lanes in the X layout);
+//   * per-wave register slabs parked as packed bf16/fp16 (C->, C<-, the <- chain's D slabs, the direct
+//     score gradients c0..c3, lse-S0).
+// Gradient flow (oracle/edgewise.py::core_bwd): dy -> dP, dSmix -> gate grads (da via MFMA on the
+// register tile, db via a 32x32 LDS transpose + MFMA) -> mean grads -> dC->, dC<- -> the two D-chains
+// (D_{m-1}^T = A_m D_m^T, row-block local) -> per view: dA_v (two GEMMs) -> softmax backward + direct +
+// mean terms -> dS_v -> dQe_v (K^T dS^T) and dK (dS^T Q through LDS) -> dq, dk, dsqk; dv from P^T dy, C->^T dy.
+#include "fused_common.h"
+
+namespace mopk {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct BwdWs {
+    unsigned char *base;     // workspace base
+    size_t stride;           // bytes per workgroup
+    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW;
+};
+enum { S_CF = 0, S_CB, S_C0, S_C1, S_C2, S_C3, S_L, S_DP, S_DL };   // S_DL .. S_DL+V-1
+
+template <int NT, int DK>
+struct BwdCfg {
+    using F = FusedCfg<NT, DK>;
+    static constexpr int NP = F::NP, LDA = F::LDA, DP = F::DP, DT = F::DT;
+    static constexpr size_t MAT = (size_t)NP * LDA * 2;
+    static constexpr size_t SLOT = (size_t)NT * 8 * 64 * 4;                // one packed slab of one wave
+    static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
+    static BwdWs carve(void *base, int V) {
+        BwdWs w{};
+        size_t o = 0;
+        w.base = (unsigned char *)base;
+        w.oT = o; o += a256((size_t)(V - 1) * MAT);
+        w.oU = o; o += a256((size_t)(V - 1) * MAT);
+        w.oKT = o; o += a256((size_t)DP * LDA * 2);
+        w.oQT = o; o += a256((size_t)DP * LDA * 2);
+        w.oDYT = o; o += a256((size_t)DP * LDA * 2);
+        w.oV0s = o; o += a256((size_t)NP * DK * 2);
+        w.oVLs = o; o += a256((size_t)NP * DK * 2);
+        w.oSlots = o; o += a256((size_t)(S_DL + V) * NT * SLOT);
+        w.oStats = o; o += a256((size_t)V * NP * 2 * 4);
+        w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
+        w.oAcc = o; o += a256((size_t)2 * NT * DT * 16 * 64 * 4);
+        w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
+        w.stride = a256(o);
+        return w;
+    }
+    // LDS: R region | Ksm | floats
+    static constexpr int R_BYTES = imax(NP * LDA * 2, 4 * NP * BTS * 2 + 2 * 32 * LDA * 2 + NT * 32 * 40 * 2);
+    static constexpr int K_BYTES = F::K_BYTES;
+    static __host__ __device__ constexpr int small_floats(int V) {
+        // sqk[8][DK] qbar kbar vs0 vsL | rCr rCl cCr cCl | colpart[NT][NP] | rS cS [V][NP] (later: dmean[2V+4][NP]) | misc
+        return 8 * DK + 4 * DK + 4 * NP + NT * NP + imax(2 * V * NP, (2 * V + 4) * NP - NT * NP) + 2 * NT * DK + 16;
+    }
+    static __host__ __device__ constexpr int lds_bytes(int V) { return R_BYTES + K_BYTES + 4 * small_floats(V); }
+};
+
+__device__ __forceinline__ u32x4 as_u4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
+__device__ __forceinline__ bf16x8 as_b8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ void pack_tile_bf(bf16x8 &lo, bf16x8 &hi, const f32x16 &x) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] = (short)f2bf(x[j]); hi[j] = (short)f2bf(x[8 + j]); }
+}
+__device__ __forceinline__ f32x16 unpack_tile_bf(bf16x8 lo, bf16x8 hi) {
+    f32x16 x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { x[j] = bf2f((unsigned short)lo[j]); x[8 + j] = bf2f((unsigned short)hi[j]); }
+    return x;
+}
+__device__ __forceinline__ void pack_tile_h(u32x4 &lo, u32x4 &hi, const f32x16 &x) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { lo[p] = pack_h2(x[2 * p], x[2 * p + 1]); hi[p] = pack_h2(x[8 + 2 * p], x[8 + 2 * p + 1]); }
+}
+__device__ __forceinline__ f32x16 unpack_tile_h(u32x4 lo, u32x4 hi) {
+    f32x16 x;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { x[2 * p] = h2_lo(lo[p]); x[2 * p + 1] = h2_hi(lo[p]); x[8 + 2 * p] = h2_lo(hi[p]); x[8 + 2 * p + 1] = h2_hi(hi[p]); }
+    return x;
+}
+__device__ __forceinline__ f32x16 zero16() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+
+template <int NT, int DK, typename IOT>
+__global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W) {
+    using Cfg = BwdCfg<NT, DK>;
+    constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = DK + 8, KS = DK / 16, DT = Cfg::DT, DP = Cfg::DP;
+    constexpr int NTH = NT * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short *R = (unsigned short *)smem;                       // [NP][LDA] matrix region
+    unsigned short *bT = R;                                           // [4][NP][BTS]           (mix phases)
+    unsigned short *bmat = bT + 4 * NP * BTS;                         // [32][LDA] rows rho: b_hi (0-15) / b_lo (16-31), k-permuted cols
+    unsigned short *amat = bmat + 32 * LDA;                           // [32][LDA] rows rho: a_hi / a_lo, natural cols
+    unsigned short *tbuf = amat + 32 * LDA;                           // [NT][32][40] per-wave 32x32 transpose buffer
+    float *dav = (float *)R;                                          // [16][NP]  (after the mix-backward loop)
+    float *dbv = dav + 16 * NP;                                       // [16][NP]
+    unsigned short *Ksm = (unsigned short *)(smem + Cfg::R_BYTES);    // [NP][LDK]
+    float *fs = (float *)(smem + Cfg::R_BYTES + Cfg::K_BYTES);
+    float *sqk = fs, *qbar = sqk + 8 * DK, *kbar = qbar + DK, *vs0 = kbar + DK, *vsL = vs0 + DK;
+    float *rCr = vsL + DK, *rCl = rCr + NP, *cCr = rCl + NP, *cCl = cCr + NP;
+    float *colpart = cCl + NP;                                        // [NT][NP]
+    float *rS = colpart + NT * NP, *cS = rS + a.V * NP;               // [V][NP]
+    float *dmean = colpart;                                           // [(2V+4)][NP] aliases colpart+rS+cS after the gate phase
+    float *redbuf = colpart + imax(NT * NP + 2 * a.V * NP, (2 * a.V + 4) * NP);   // [2][NT][DK]
+    float *misc = redbuf + 2 * NT * DK;                               // wsig, ...
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int N = a.N, V = a.V, H = a.H, RK = a.r;
+    const int b = blockIdx.x / H, hh = blockIdx.x % H;
+    const int qi = 32 * w + r;
+    const bool qok = qi < N;
+    const float invN = 1.f / (float)N;
+    const int C = 2 * V + 2;
+
+    unsigned char *ws = W.base + (size_t)blockIdx.x * W.stride;
+    unsigned short *Tg = (unsigned short *)(ws + W.oT), *Ug = (unsigned short *)(ws + W.oU);
+    unsigned short *KT = (unsigned short *)(ws + W.oKT), *QT = (unsigned short *)(ws + W.oQT), *DYT = (unsigned short *)(ws + W.oDYT);
+    unsigned short *V0s = (unsigned short *)(ws + W.oV0s), *VLs = (unsigned short *)(ws + W.oVLs);
+    float *stats = (float *)(ws + W.oStats);                          // [V][NP][2]  (row max, 1/row sum)
+    float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
+    float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)NT * DT * 16 * 64;
+    float *dwp = (float *)(ws + W.oDW);
+    auto slot = [&](int s) -> u32x4 * { return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane; };
+    // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
+
+    const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
+    const IOT *dyrow = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)qi * a.dy.sn;
+    const float *ych = (const float *)a.saved + (size_t)blockIdx.x * N * DK;   // w * y_chain from the fused forward
+
+    // ================= P0: stage operands =================
+    {
+        const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh;
+        const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
+        const IOT *dp = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh;
+        const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
+        const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
+        for (int c = tid; c < V * DK; c += NTH) sqk[c] = a.sqk[((c / DK) * H + hh) * DK + (c % DK)];
+        for (int c = tid; c < DK; c += NTH) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
+        if (tid == 0) misc[0] = 1.f / (1.f + __expf(-*a.chain_logit));
+        constexpr int CH = DK / 8;
+        for (int c = tid; c < NP * CH; c += NTH) {
+            const int j = c / CH, dc = c % CH;
+            bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, qv = kv, dv = kv, x0 = kv, xL = kv;
+            if (j < N) {
+                kv = load8_bf16<IOT>(kp + (int64_t)j * a.k.sn + dc * 8);
+                qv = load8_bf16<IOT>(qp + (int64_t)j * a.q.sn + dc * 8);
+                dv = load8_bf16<IOT>(dp + (int64_t)j * a.dy.sn + dc * 8);
+                x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8);
+                xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8);
+            }
+            *(bf16x8 *)&Ksm[j * LDK + dc * 8] = kv;
+            const int col = (j & ~15) + kperm16(j & 15);
+            bf16x8 s0, sL;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = dc * 8 + e;
+                KT[d * LDA + col] = (unsigned short)kv[e];
+                QT[d * LDA + col] = (unsigned short)qv[e];
+                DYT[d * LDA + col] = (unsigned short)dv[e];
+                s0[e] = (short)f2bf(bf2f((unsigned short)x0[e]) * a.vs0[hh * DK + d]);
+                sL[e] = (short)f2bf(bf2f((unsigned short)xL[e]) * a.vsL[hh * DK + d]);
+            }
+            *(bf16x8 *)&V0s[j * DK + dc * 8] = s0;
+            *(bf16x8 *)&VLs[j * DK + dc * 8] = sL;
+        }
+        if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NTH) { KT[DK * LDA + c] = 0; QT[DK * LDA + c] = 0; DYT[DK * LDA + c] = 0; }
+    }
+    {   // per-wave partial of qbar
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(qrow + 16 * s + 8 * h); qf[s] = v; }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = half_sum32(bf2f((unsigned short)qf[s][j])); if (r == 0) colpart[w * DK + 16 * s + 8 * h + j] = t; }
+        __syncthreads();
+        if (tid < DK) {
+            float sk = 0.f, sq = 0.f;
+            for (int j = 0; j < N; ++j) sk += bf2f(Ksm[j * LDK + tid]);
+            for (int ww = 0; ww < NT; ++ww) sq += colpart[ww * DK + tid];
+            kbar[tid] = sk * invN; qbar[tid] = sq * invN;
+        }
+        __syncthreads();
+        for (int v = 0; v < V; ++v) {
+            float p = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int d = 16 * s + 8 * h + j; p = fmaf(bf2f((unsigned short)qf[s][j]) * sqk[v * DK + d], kbar[d], p); }
+            p += __shfl_xor(p, 32, 64);
+            if (h == 0) rS[v * NP + qi] = p;
+            if (tid < NP) {
+                float c = 0.f;
+                for (int d = 0; d < DK; ++d) c = fmaf(bf2f(Ksm[tid * LDK + d]) * sqk[v * DK + d], qbar[d], c);
+                cS[v * NP + tid] = c;
+            }
+        }
+    }
+    const float wv = misc[0];
+
+    // ================= helpers =================
+    auto make_frag = [&](bf16x8 (&qe)[KS], const IOT *row, const float *scale) {   // B fragments of a (q|dy) row, optional d-scale
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qok) qv = load8_bf16<IOT>(row + 16 * s + 8 * h);
+            if (scale) {
+                const float4 s0 = *(const float4 *)&scale[16 * s + 8 * h], s1 = *(const float4 *)&scale[16 * s + 8 * h + 4];
+                const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qv[j] = (short)f2bf(bf2f((unsigned short)qv[j]) * sc[j]);
+            }
+            qe[s] = qv;
+        }
+    };
+    auto s_tile = [&](const bf16x8 (&qe)[KS], int t) -> f32x16 {                   // S^T tile [key, query] from K in LDS
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 af = *(const bf16x8 *)&Ksm[(32 * t + r) * LDK + 16 * s + 8 * h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qe[s], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto g_tile = [&](const unsigned short *Arows, const bf16x8 (&fr)[KS], int t) -> f32x16 {   // (Arows[j,:] . frag) tile, A from global [NP][DK]
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 af = *(const bf16x8 *)&Arows[(32 * t + r) * DK + 16 * s + 8 * h];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, fr[s], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    auto a_slab = [&](f32x16 (&X)[NT], int v) {     // softmax_j(S_v^T) slab + row stats
+        bf16x8 qe[KS];
+        make_frag(qe, qrow, sqk + v * DK);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            X[t] = s_tile(qe, t);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { if (32 * t + tile_row(g, h) >= N) X[t][g] = -INFINITY; mx = fmaxf(mx, X[t][g]); }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sm = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { const float e = __expf(X[t][g] - mx); X[t][g] = e; sm += e; }
+        sm += __shfl_xor(sm, 32, 64);
+        const float inv = 1.f / sm;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) X[t] *= inv;
+        if (h == 0) { stats[(v * NP + qi) * 2] = mx; stats[(v * NP + qi) * 2 + 1] = inv; }
+    };
+    auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float mx, float inv) -> f32x16 {   // one tile of A_v^T from saved stats
+        f32x16 s = s_tile(qe, t);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s[g] = (32 * t + tile_row(g, h) < N) ? __expf(s[g] - mx) * inv : 0.f;
+        return s;
+    };
+    // form (i): dst[j][perm(i)] = X^T slab (A operand for products contracting over QUERIES)
+    auto store_i = [&](unsigned short *dst, const f32x16 (&X)[NT]) {
+        const int col = 32 * w + 16 * (r >> 4) + kperm16(r & 15);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) dst[(32 * t + tile_row(g, h)) * LDA + col] = f2bf(X[t][g]);
+    };
+    auto store_i_tile = [&](unsigned short *dst, int t, bf16x8 lo, bf16x8 hi) {
+        const int col = 32 * w + 16 * (r >> 4) + kperm16(r & 15);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            dst[(32 * t + tile_row(g, h)) * LDA + col] = (unsigned short)lo[g];
+            dst[(32 * t + tile_row(8 + g, h)) * LDA + col] = (unsigned short)hi[g];
+        }
+    };
+    // form (ii): dst[i][perm(j)] = slab rows (A operand for products contracting over KEYS)
+    auto store_ii = [&](unsigned short *dst, const f32x16 (&X)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                // regs 4g4..4g4+3 <-> keys 32t + 8g4 + 4h + {0..3}; permuted position keeps the low 2 bits
+                const int j0 = 32 * t + 8 * g4 + 4 * h;
+                const int col = (j0 & ~15) + kperm16(j0 & 15);
+                *(uint2 *)&dst[qi * LDA + col] = make_uint2(pack_bf16(X[t][4 * g4], X[t][4 * g4 + 1]), pack_bf16(X[t][4 * g4 + 2], X[t][4 * g4 + 3]));
+            }
+    };
+    auto gemm_lds_reg = [&](f32x16 (&Xn)[NT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
+#pragma unroll
+        for (int to = 0; to < NT; ++to) {
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * to + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
+                }
+            Xn[to] = acc;
+        }
+    };
+    // acc[to] += sum_i Am[j][i] * Bm[k][i]   (A rows j from LDS, B rows k = this lane's query from a global AT-format image)
+    auto gemm_lds_glob = [&](f32x16 (&acc)[NT], const unsigned short *Am, const unsigned short *Bm) {
+        const unsigned short *brow = Bm + (size_t)qi * LDA;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 bfr = *(const bf16x8 *)&brow[32 * t + 16 * s + 8 * h];
+#pragma unroll
+                for (int to = 0; to < NT; ++to) {
+                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * to + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[to], 0, 0, 0);
+                }
+            }
+    };
+    // out[dt] = Am[d][:] . Xp   (A rows d from a [DP][LDA] image, contraction over the slab's rows)
+    auto gemm_small = [&](f32x16 (&out)[DT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
+                }
+            out[dt] = acc;
+        }
+    };
+    // out[dt] = sum_i Am[32w + r][i] * Bm[d][i]   (rows of this wave's tile of an LDS AT image, B rows d from global)
+    auto gemm_rows_glob = [&](f32x16 (&out)[DT], const unsigned short *Am, const unsigned short *Bm) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) out[dt] = zero16();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 af = *(const bf16x8 *)&Am[(32 * w + r) * LDA + 32 * t + 16 * s + 8 * h];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 bfr = *(const bf16x8 *)&Bm[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, out[dt], 0, 0, 0);
+                }
+            }
+    };
+    auto pack_all = [&](bf16x8 (&Xp)[NT][2], const f32x16 (&X)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pack_tile_bf(Xp[t][0], Xp[t][1], X[t]);
+    };
+    auto slot_st = [&](int s, const bf16x8 (&Xp)[NT][2]) {
+        u32x4 *p = slot(s);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { p[(2 * t) * 64] = as_u4(Xp[t][0]); p[(2 * t + 1) * 64] = as_u4(Xp[t][1]); }
+    };
+    auto slot_ld = [&](int s, bf16x8 (&Xp)[NT][2]) {
+        const u32x4 *p = slot(s);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(p[(2 * t) * 64]); Xp[t][1] = as_b8(p[(2 * t + 1) * 64]); }
+    };
+    auto log_means = [&](f32x16 (&X)[NT], float *rout) {   // X <- log(X+eps); row means; per-wave column partials
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float c[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float v = __logf(X[t][g] + EPSC);
+                X[t][g] = v;
+                rs += (32 * t + tile_row(g, h) < N) ? v : 0.f;
+                c[g] = qok ? v : 0.f;
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int n = 8 >> st;
+                const bool up = (r >> (4 - st)) & 1;
+#pragma unroll
+                for (int k = 0; k < n; ++k) {
+                    const float keep = up ? c[k + n] : c[k], send = up ? c[k] : c[k + n];
+                    c[k] = keep + __shfl_xor(send, 16 >> st, 64);
+                }
+            }
+            c[0] += __shfl_xor(c[0], 1, 64);
+            if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        if (h == 0) rout[qi] = rs * invN;
+    };
+    // forward chain recompute; every prefix product (m = 0..V-2) is written to Pg[m] in AT format
+    auto run_chain = [&](f32x16 (&X)[NT], bool forward, unsigned short *Pg) {
+        bf16x8 Xp[NT][2];
+        a_slab(X, forward ? 0 : V - 1);
+        for (int m = 1; m < V; ++m) {
+            pack_all(Xp, X);
+            {
+                unsigned short *dst = Pg + (size_t)(m - 1) * NP * LDA;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) store_i_tile(dst, t, Xp[t][0], Xp[t][1]);
+            }
+            a_slab(X, forward ? m : V - 1 - m);
+            __syncthreads();
+            store_i(R, X);
+            __syncthreads();
+            gemm_lds_reg(X, R, Xp);
+        }
+    };
+
+    f32x16 X[NT];
+    // ================= P1/P2: forward chains (recompute) =================
+    __syncthreads();                     // P0 global images + LDS complete
+    run_chain(X, false, Ug);
+    {
+        bf16x8 Xp[NT][2];
+        pack_all(Xp, X);
+        slot_st(S_CB, Xp);
+    }
+    log_means(X, rCl);
+    __syncthreads();
+    if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
+    run_chain(X, true, Tg);
+    {
+        bf16x8 Xp[NT][2];
+        pack_all(Xp, X);
+        slot_st(S_CF, Xp);
+    }
+    log_means(X, rCr);
+    unsigned int crp[NT][8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(X[t][2 * p], X[t][2 * p + 1]);
+    __syncthreads();
+    if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
+    __syncthreads();
+    // ================= P3: gate vectors =================
+    if (tid < NP) {
+        const int j = tid;
+        const int col = (j & ~15) + kperm16(j & 15);
+        for (int g = 0; g < 4; ++g) {
+            unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+            if (j < N)
+                for (int k = 0; k < RK; ++k) {
+                    const int o = g * RK + k;
+                    float s = a.bc[o];
+                    for (int c = 0; c < C; ++c) {
+                        const float f = c < V ? cS[c * NP + j] : (c < 2 * V ? rS[(c - V) * NP + j] : (c == 2 * V ? cCr[j] : cCl[j]));
+                        s = fmaf(a.Wc[o * C + c], f, s);
+                    }
+                    hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
+                }
+            unsigned short *row = bT + (g * NP + j) * BTS;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0;
+                bmat[(4 * g + k) * LDA + col] = hi[k];
+                bmat[(16 + 4 * g + k) * LDA + col] = lo[k];
+            }
+        }
+    }
+    bf16x8 af4[4];
+    for (int g = 0; g < 4; ++g) {
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < RK; ++k) {
+            const int o = g * RK + k;
+            float s = a.br[o];
+            for (int c = 0; c < C; ++c) {
+                const float f = c < V ? rS[c * NP + qi] : (c < 2 * V ? cS[(c - V) * NP + qi] : (c == 2 * V ? rCr[qi] : rCl[qi]));
+                s = fmaf(a.Wr[o * C + c], f, s);
+            }
+            av[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned short hi = f2bf(av[k]), lo = f2bf(av[k] - bf2f(hi));
+            af4[g][k] = (short)hi;
+            af4[g][4 + k] = h == 0 ? (short)lo : (short)0;
+            if (h == 0) { amat[(4 * g + k) * LDA + qi] = qok ? hi : (unsigned short)0; amat[(16 + 4 * g + k) * LDA + qi] = qok ? lo : (unsigned short)0; }
+        }
+    }
+    __syncthreads();
+    // ================= P4: mix recompute -> Smix (crp), L parked =================
+    const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
+    auto gate_tile = [&](int t, int g4) -> f32x16 {
+        const bf16x8 bfrag = *(const bf16x8 *)&bT[(g4 * NP + 32 * t + r) * BTS + 8 * h];
+        f32x16 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, af4[g4], zero16(), 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) z[g] = 1.f / (1.f + __expf(-z[g]));
+        return z;
+    };
+    auto crp_get = [&](unsigned int (&cw)[8], int t) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) if (t == k) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) cw[p] = crp[k][p];
+        }
+    };
+    auto crp_set = [&](int t, const unsigned int (&cw)[8]) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) if (t == k) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) crp[k][p] = cw[p];
+        }
+    };
+    float mxrow = -INFINITY;
+#pragma nounroll
+    for (int t = 0; t < NT; ++t) {
+        unsigned int cw[8];
+        crp_get(cw, t);
+        f32x16 S0, O, L;
+        {
+            bf16x8 qe[KS];
+            make_frag(qe, qrow, sqk);
+            S0 = s_tile(qe, t);
+            f32x16 mx = zero16(), se;
+            O = mx;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) se[g] = 1.f;
+            for (int v = 1; v < V; ++v) {
+                make_frag(qe, qrow, sqk + v * DK);
+                const f32x16 Sv = s_tile(qe, t);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    O[g] += Sv[g];
+                    const float d = Sv[g] - S0[g];
+                    const float e = __expf(-fabsf(d - mx[g]));
+                    se[g] = d > mx[g] ? fmaf(se[g], e, 1.f) : se[g] + e;
+                    mx[g] = fmaxf(mx[g], d);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) L[g] = mx[g] + __logf(se[g]);
+        }
+        {
+            u32x4 lo, hi;
+            pack_tile_h(lo, hi, L);
+            u32x4 *p = slot(S_L);
+            p[(2 * t) * 64] = lo; p[(2 * t + 1) * 64] = hi;
+        }
+        { const f32x16 G = gate_tile(t, 0);
+#pragma unroll
+          for (int g = 0; g < 16; ++g) S0[g] = fmaf(G[g], O[g], S0[g]); }
+        { const f32x16 G = gate_tile(t, 1);
+#pragma unroll
+          for (int g = 0; g < 16; ++g) S0[g] = fmaf(G[g], L[g], S0[g]); }
+        { const f32x16 G = gate_tile(t, 2);
+#pragma unroll
+          for (int g = 0; g < 16; ++g) S0[g] = fmaf(-nb * G[g], O[g], S0[g]); }
+        { const f32x16 G = gate_tile(t, 3);
+#pragma unroll
+          for (int p = 0; p < 8; ++p) {
+              float s0 = fmaf(G[2 * p], h2_lo(cw[p]), S0[2 * p]);
+              float s1 = fmaf(G[2 * p + 1], h2_hi(cw[p]), S0[2 * p + 1]);
+              if (32 * t + tile_row(2 * p, h) >= N) s0 = -INFINITY;
+              if (32 * t + tile_row(2 * p + 1, h) >= N) s1 = -INFINITY;
+              mxrow = fmaxf(mxrow, fmaxf(s0, s1));
+              cw[p] = pack_h2(s0, s1);
+          } }
+        crp_set(t, cw);
+    }
+    mxrow = fmaxf(mxrow, __shfl_xor(mxrow, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) lsum += __expf(h2_lo(crp[t][p]) - mxrow) + __expf(h2_hi(crp[t][p]) - mxrow);
+    lsum += __shfl_xor(lsum, 32, 64);
+    const float invl = 1.f / lsum;
+    auto p_tile = [&](const unsigned int (&cw)[8]) -> f32x16 {      // P tile from packed Smix
+        f32x16 p;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { p[2 * q] = __expf(h2_lo(cw[q]) - mxrow) * invl; p[2 * q + 1] = __expf(h2_hi(cw[q]) - mxrow) * invl; }
+        return p;
+    };
+    // ================= P5: delta_i = sum_j P dP =================
+    bf16x8 dyf[KS];
+    make_frag(dyf, dyrow, nullptr);
+    float delta = 0.f;
+#pragma nounroll
+    for (int t = 0; t < NT; ++t) {
+        unsigned int cw[8];
+        crp_get(cw, t);
+        const f32x16 P = p_tile(cw);
+        const f32x16 dP = g_tile(V0s, dyf, t);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) delta = fmaf(P[g], dP[g], delta);
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    // ================= P6: mix backward =================
+    f32x16 daacc = zero16();
+    unsigned short *tb = tbuf + w * 32 * 40;
+#pragma nounroll
+    for (int t = 0; t < NT; ++t) {
+        unsigned int cw[8];
+        crp_get(cw, t);
+        f32x16 dS;                                   // dSmix tile
+        {
+            const f32x16 P = p_tile(cw);
+            const f32x16 dP = g_tile(V0s, dyf, t);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) dS[g] = (32 * t + tile_row(g, h) < N) ? P[g] * (dP[g] - delta) : 0.f;
+        }
+        f32x16 O = zero16();
+        {
+            bf16x8 qe[KS];
+            for (int v = 1; v < V; ++v) {
+                make_frag(qe, qrow, sqk + v * DK);
+                const f32x16 Sv = s_tile(qe, t);
+                O += Sv;
+            }
+        }
+        f32x16 L, Cr;
+        {
+            const u32x4 *p = slot(S_L);
+            L = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);
+            const u32x4 *pc = slot(S_CF);
+            Cr = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
+#pragma unroll
+            for (int g = 0; g < 16; ++g) Cr[g] = __logf(Cr[g] + EPSC);
+        }
+        f32x16 c0 = dS, c1 = zero16(), dbt = zero16();
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x16 G = gate_tile(t, g4);
+            f32x16 dZ;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float term = g4 == 0 ? O[g] : (g4 == 1 ? L[g] : (g4 == 2 ? -nb * O[g] : Cr[g]));
+                dZ[g] = dS[g] * term * G[g] * (1.f - G[g]);
+            }
+            if (g4 == 0) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) c1[g] = dS[g] * G[g];
+            } else if (g4 == 1) {
+                u32x4 lo, hi; bf16x8 bl, bh;
+                f32x16 c2;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { c2[g] = dS[g] * G[g]; c0[g] -= c2[g]; }
+                pack_tile_bf(bl, bh, c2);
+                u32x4 *p = slot(S_C2); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
+                pack_tile_bf(bl, bh, c0);
+                p = slot(S_C0); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
+                (void)lo; (void)hi;
+            } else if (g4 == 2) {
+                bf16x8 bl, bh;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) c1[g] -= nb * dS[g] * G[g];
+                pack_tile_bf(bl, bh, c1);
+                u32x4 *p = slot(S_C1); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
+            } else {
+                bf16x8 bl, bh;
+                f32x16 c3;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) c3[g] = dS[g] * G[g];
+                pack_tile_bf(bl, bh, c3);
+                u32x4 *p = slot(S_C3); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
+            }
+            // da[rho, i] += sum_j bmat_g[rho][j] dZ^T[j, i]      (rows of gate g4 only)
+            bf16x8 zl, zh;
+            pack_tile_bf(zl, zh, dZ);
+            {
+                const bool mine = ((r >> 2) & 3) == g4;           // rows 4g4..4g4+3 (hi) and 16+4g4.. (lo)
+                bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
+                if (mine) {
+                    a0 = *(const bf16x8 *)&bmat[r * LDA + 32 * t + 8 * h];
+                    a1 = *(const bf16x8 *)&bmat[r * LDA + 32 * t + 16 + 8 * h];
+                }
+                daacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, zl, daacc, 0, 0, 0);
+                daacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, zh, daacc, 0, 0, 0);
+            }
+            // db[rho, j] (this wave's queries) = sum_i amat_g[rho][i] dZ[i, j] : transpose the tile through LDS
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                tb[tile_row(g, h) * 40 + r] = (unsigned short)zl[g];
+                tb[tile_row(8 + g, h) * 40 + r] = (unsigned short)zh[g];
+            }
+            {
+                const bool mine = ((r >> 2) & 3) == g4;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 aa = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (mine) aa = *(const bf16x8 *)&amat[r * LDA + 32 * w + 16 * s + 8 * h];
+                    const bf16x8 bb = *(const bf16x8 *)&tb[r * 40 + 16 * s + 8 * h];
+                    dbt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, dbt, 0, 0, 0);
+                }
+            }
+        }
+        // dbt rows rho (hi: regs 0-7, lo: regs 8-15), lanes = keys of tile t
+#pragma unroll
+        for (int g = 0; g < 8; ++g) dbp[((size_t)w * 16 + tile_row(g, h)) * NP + 32 * t + r] = dbt[g] + dbt[8 + g];
+    }
+    __syncthreads();                                   // bT / bmat / amat / tbuf dead; dbp complete
+#pragma unroll
+    for (int g = 0; g < 8; ++g) dav[tile_row(g, h) * NP + qi] = daacc[g] + daacc[8 + g];
+    for (int c = tid; c < 16 * NP; c += NTH) {
+        float s = 0.f;
+        for (int ww = 0; ww < NT; ++ww) s += dbp[(size_t)ww * 16 * NP + c];
+        dbv[c] = s;
+    }
+    __syncthreads();
+    // ================= P7: gradients of the gate-head inputs / weights =================
+    {
+        // dW partials first (they read rS/cS which dmean is about to overwrite)
+        const int nO = 4 * RK;
+        for (int idx = tid; idx < 2 * nO * (C + 1); idx += NTH) {
+            const int side = idx / (nO * (C + 1)), rem = idx % (nO * (C + 1));
+            const int o = rem / (C + 1), c = rem % (C + 1);
+            const int rho = 4 * (o / RK) + (o % RK);
+            const float *g = (side ? dbv : dav) + rho * NP;
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) {
+                float f = 1.f;
+                if (c < C) {
+                    if (side == 0) f = c < V ? rS[c * NP + n] : (c < 2 * V ? cS[(c - V) * NP + n] : (c == 2 * V ? rCr[n] : rCl[n]));
+                    else f = c < V ? cS[c * NP + n] : (c < 2 * V ? rS[(c - V) * NP + n] : (c == 2 * V ? cCr[n] : cCl[n]));
+                }
+                s = fmaf(g[n], f, s);
+            }
+            dwp[idx] = s;
+        }
+        __syncthreads();
+        if (tid < NP) {
+            const int n = tid;
+            float drow[18], dcol[18];
+            for (int c = 0; c < C; ++c) { drow[c] = 0.f; dcol[c] = 0.f; }
+            if (n < N)
+                for (int o = 0; o < 4 * RK; ++o) {
+                    const int rho = 4 * (o / RK) + (o % RK);
+                    const float va = dav[rho * NP + n], vb = dbv[rho * NP + n];
+                    for (int c = 0; c < C; ++c) { drow[c] = fmaf(a.Wr[o * C + c], va, drow[c]); dcol[c] = fmaf(a.Wc[o * C + c], vb, dcol[c]); }
+                }
+            // dmean rows: [0,V) drS_v ; [V,2V) dcS_v ; 2V drCr ; 2V+1 dcCr ; 2V+2 drCl ; 2V+3 dcCl   (pre-divided by N)
+            for (int v = 0; v < V; ++v) {
+                dmean[v * NP + n] = (drow[v] + dcol[V + v]) * invN;
+                dmean[(V + v) * NP + n] = (drow[V + v] + dcol[v]) * invN;
+            }
+            dmean[(2 * V) * NP + n] = drow[2 * V] * invN; dmean[(2 * V + 1) * NP + n] = dcol[2 * V] * invN;
+            dmean[(2 * V + 2) * NP + n] = drow[2 * V + 1] * invN; dmean[(2 * V + 3) * NP + n] = dcol[2 * V + 1] * invN;
+        }
+        __syncthreads();
+    }
+    // ================= P8: dv0 = P^T dy, dvL = w C->^T dy =================
+    {
+#pragma nounroll
+        for (int t = 0; t < NT; ++t) {
+            unsigned int cw[8];
+            crp_get(cw, t);
+            const f32x16 P = p_tile(cw);
+            bf16x8 lo, hi;
+            pack_tile_bf(lo, hi, P);
+            store_i_tile(R, t, lo, hi);
+        }
+        __syncthreads();
+        f32x16 g0[DT], gL[DT];
+        gemm_rows_glob(g0, R, DYT);                    // dV0e[j in tile w][d]
+        __syncthreads();
+        {
+            bf16x8 Xp[NT][2];
+            slot_ld(S_CF, Xp);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) store_i_tile(R, t, Xp[t][0], Xp[t][1]);
+        }
+        __syncthreads();
+        gemm_rows_glob(gL, R, DYT);                    // (C->^T dy)[j][d]
+        __syncthreads();
+        const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
+        const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
+        IOT *d0p = (IOT *)a.dv0.ptr + b * a.dv0.sb + hh * a.dv0.sh;
+        IOT *dLp = (IOT *)a.dvL.ptr + b * a.dvL.sb + hh * a.dvL.sh;
+        const bool same = a.dv0.ptr == a.dvL.ptr;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 32 * dt + r;                 // lanes <-> d, registers <-> keys of tile w
+            float s0 = 0.f, sL = 0.f;
+            if (d < DK) {
+                const float f0 = vs0[d], fL = vsL[d] * wv;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int j = 32 * w + tile_row(g, h);
+                    if (j < N) {
+                        const float e0 = g0[dt][g], eL = gL[dt][g] * wv;
+                        s0 = fmaf(e0, ld_as_f32(v0p + (int64_t)j * a.v0.sn + d), s0);
+                        sL = fmaf(eL, ld_as_f32(vLp + (int64_t)j * a.vL.sn + d), sL);
+                        if (same) st_from_f32(d0p + (int64_t)j * a.dv0.sn + d, e0 * f0 + gL[dt][g] * fL);
+                        else { st_from_f32(d0p + (int64_t)j * a.dv0.sn + d, e0 * f0); st_from_f32(dLp + (int64_t)j * a.dvL.sn + d, gL[dt][g] * fL); }
+                    }
+                }
+                s0 += __shfl_xor(s0, 32, 64); sL += __shfl_xor(sL, 32, 64);
+                if (h == 0) { redbuf[w * DK + d] = s0; redbuf[(NT + w) * DK + d] = sL; }
+            }
+        }
+        __syncthreads();
+        if (tid < DK) {
+            float s0 = 0.f, sL = 0.f;
+            for (int ww = 0; ww < NT; ++ww) { s0 += redbuf[ww * DK + tid]; sL += redbuf[(NT + ww) * DK + tid]; }
+            a.dvs0_part[((int64_t)b * H + hh) * DK + tid] = s0;
+            a.dvsL_part[((int64_t)b * H + hh) * DK + tid] = sL;
+        }
+        // dlogit_part = (1-w) sum dy * (w y_chain)
+        float dl = 0.f;
+        if (qok) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl = fmaf(bf2f((unsigned short)dyf[s][j]), ych[(size_t)qi * DK + 16 * s + 8 * h + j], dl);
+        }
+        dl = wave_sum(dl);
+        if (lane == 0) misc[4 + w] = dl;
+        __syncthreads();
+        if (tid == 0) { float s = 0.f; for (int ww = 0; ww < NT; ++ww) s += misc[4 + ww]; a.dlogit_part[(int64_t)b * H + hh] = s * (1.f - wv); }
+    }
+    // ================= P9: <- chain backward: D'_m slabs parked in S_DL+m =================
+    {
+        const float drl = dmean[(2 * V + 2) * NP + qi];
+        {
+            bf16x8 Xp[NT][2];
+            slot_ld(S_CB, Xp);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x16 cb = unpack_tile_bf(Xp[t][0], Xp[t][1]);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int j = 32 * t + tile_row(g, h);
+                    X[t][g] = (j < N && qok) ? (drl + dmean[(2 * V + 3) * NP + j]) / (cb[g] + EPSC) : 0.f;
+                }
+            }
+        }
+        for (int m = V - 1; m >= 1; --m) {
+            bf16x8 Dp[NT][2];
+            pack_all(Dp, X);
+            slot_st(S_DL + m, Dp);
+            a_slab(X, V - 1 - m);                      // A_av slab (rows = my queries)
+            __syncthreads();
+            store_ii(R, X);
+            __syncthreads();
+            gemm_lds_reg(X, R, Dp);                    // D'_{m-1}^T = A_av D'_m^T
+        }
+        bf16x8 Dp[NT][2];
+        pack_all(Dp, X);
+        slot_st(S_DL, Dp);
+    }
+    // ================= P10: -> chain backward with per-view totals =================
+    {
+        // dC->^T slab
+        {
+            const float drr = dmean[(2 * V) * NP + qi];
+            bf16x8 Cp[NT][2], C3[NT][2];
+            slot_ld(S_CF, Cp);
+            slot_ld(S_C3, C3);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x16 cf = unpack_tile_bf(Cp[t][0], Cp[t][1]);
+                const f32x16 c3 = unpack_tile_bf(C3[t][0], C3[t][1]);
+                const f32x16 dyv = g_tile(VLs, dyf, t);          // (dy vL^T)^T tile
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int j = 32 * t + tile_row(g, h);
+                    X[t][g] = (j < N && qok) ? (c3[g] + drr + dmean[(2 * V + 1) * NP + j]) / (cf[g] + EPSC) + wv * dyv[g] : 0.f;
+                }
+            }
+        }
+        bf16x8 Dp[NT][2];
+        pack_all(Dp, X);
+        for (int v = V - 1; v >= 0; --v) {
+            slot_st(S_DP, Dp);                         // park D_v (B operand of the D-chain step below)
+            // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index)
+            if (v >= 1) {
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < NT; ++t) store_i_tile(R, t, Dp[t][0], Dp[t][1]);
+                __syncthreads();
+#pragma unroll
+                for (int t = 0; t < NT; ++t) X[t] = zero16();
+                gemm_lds_glob(X, R, Tg + (size_t)(v - 1) * NP * LDA);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) X[t] = unpack_tile_bf(Dp[t][0], Dp[t][1]);
+            }
+            {
+                const int mp = V - 1 - v;
+                bf16x8 Dl[NT][2];
+                slot_ld(S_DL + mp, Dl);
+                if (mp >= 1) {
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) store_i_tile(R, t, Dl[t][0], Dl[t][1]);
+                    __syncthreads();
+                    gemm_lds_glob(X, R, Ug + (size_t)(mp - 1) * NP * LDA);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) X[t] += unpack_tile_bf(Dl[t][0], Dl[t][1]);
+                }
+            }
+            // ---- softmax backward + direct + mean terms -> dS_v^T (in place)
+            {
+                const float smx = stats[(v * NP + qi) * 2], sinv = stats[(v * NP + qi) * 2 + 1];
+                bf16x8 qe[KS], qe0[KS];
+                make_frag(qe, qrow, sqk + v * DK);
+                float dot = 0.f;
+#pragma nounroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x16 A = a_tile(qe, t, smx, sinv);
+                    const f32x16 dA = tile_get<NT>(X, t);
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dA[g], dot);
+                }
+                dot += __shfl_xor(dot, 32, 64);
+                if (v != 0) make_frag(qe0, qrow, sqk);
+                const float drs = dmean[v * NP + qi];
+#pragma nounroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x16 Sv = s_tile(qe, t);
+                    f32x16 pi;
+                    {
+                        const u32x4 *p = slot(S_L);
+                        const f32x16 L = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);
+                        if (v != 0) {
+                            const f32x16 S0 = s_tile(qe0, t);
+#pragma unroll
+                            for (int g = 0; g < 16; ++g) pi[g] = __expf(Sv[g] - S0[g] - L[g]);
+                        } else {
+#pragma unroll
+                            for (int g = 0; g < 16; ++g) pi[g] = __expf(-L[g]);
+                        }
+                    }
+                    const u32x4 *pc = slot(v == 0 ? S_C0 : S_C1);
+                    const u32x4 *p2 = slot(S_C2);
+                    const f32x16 cd = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
+                    const f32x16 c2 = unpack_tile_bf(as_b8(p2[(2 * t) * 64]), as_b8(p2[(2 * t + 1) * 64]));
+                    const f32x16 dA = tile_get<NT>(X, t);
+                    f32x16 dS;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        const int j = 32 * t + tile_row(g, h);
+                        const float A = __expf(Sv[g] - smx) * sinv;
+                        dS[g] = j < N ? A * (dA[g] - dot) + cd[g] + c2[g] * pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
+                    }
+                    tile_set<NT>(X, t, dS);
+                }
+            }
+            // ---- dQe_v^T = K^T dS^T ; dq += sqk_v * dQe_v ; dsqk_v = sum_i q * dQe_v
+            bf16x8 Sp[NT][2];
+            pack_all(Sp, X);
+            {
+                f32x16 dq[DT];
+                gemm_small(dq, KT, Sp);
+                float *acc = dqacc + ((size_t)w * DT * 16) * 64 + lane;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    float c[16];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int d0 = 32 * dt + 8 * g4 + 4 * h;
+                        float qv[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (qok && d0 < DK) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) qv[e] = ld_as_f32(qrow + d0 + e);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int g = 4 * g4 + e;
+                            const float sc = d0 < DK ? sqk[v * DK + d0 + e] : 0.f;
+                            float *p = acc + (size_t)(dt * 16 + g) * 64;
+                            const float prev = v == V - 1 ? 0.f : *p;
+                            *p = fmaf(sc, dq[dt][g], prev);
+                            c[g] = qok ? qv[e] * dq[dt][g] : 0.f;
+                        }
+                    }
+                    // reduce over the 32 queries of this half (butterfly), lane r even holds register r>>1
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const int n = 8 >> st;
+                        const bool up = (r >> (4 - st)) & 1;
+#pragma unroll
+                        for (int k = 0; k < n; ++k) {
+                            const float keep = up ? c[k + n] : c[k], send = up ? c[k] : c[k + n];
+                            c[k] = keep + __shfl_xor(send, 16 >> st, 64);
+                        }
+                    }
+                    c[0] += __shfl_xor(c[0], 1, 64);
+                    const int d = 32 * dt + tile_row(r >> 1, h);
+                    if ((r & 1) == 0 && d < DK) redbuf[w * DK + d] = c[0];
+                }
+            }
+            // ---- dK += sqk_v * (dS^T Q) through LDS
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) store_i_tile(R, t, Sp[t][0], Sp[t][1]);
+            __syncthreads();
+            if (tid < DK) {
+                float s = 0.f;
+                for (int ww = 0; ww < NT; ++ww) s += redbuf[ww * DK + tid];
+                a.dsqk_part[(((int64_t)b * V + v) * H + hh) * DK + tid] = s;
+            }
+            {
+                f32x16 dk[DT];
+                gemm_rows_glob(dk, R, QT);             // (dS^T q)[j in tile w][d]
+                float *acc = dkacc + ((size_t)w * DT * 16) * 64 + lane;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const int d = 32 * dt + r;
+                    const float sc = d < DK ? sqk[v * DK + d] : 0.f;
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) {
+                        float *p = acc + (size_t)(dt * 16 + g) * 64;
+                        const float prev = v == V - 1 ? 0.f : *p;
+                        *p = fmaf(sc, dk[dt][g], prev);
+                    }
+                }
+            }
+            // ---- D_{v-1}^T = A_v D_v^T
+            if (v >= 1) {
+                a_slab(X, v);
+                __syncthreads();
+                store_ii(R, X);
+                __syncthreads();
+                slot_ld(S_DP, Dp);
+                gemm_lds_reg(X, R, Dp);
+                pack_all(Dp, X);
+            }
+        }
+    }
+    // ================= P11: write dq, dk =================
+    {
+        IOT *dqp = (IOT *)a.dq.ptr + b * a.dq.sb + hh * a.dq.sh + (int64_t)qi * a.dq.sn;
+        const float *acc = dqacc + ((size_t)w * DT * 16) * 64 + lane;
+        if (qok) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int d0 = 32 * dt + 8 * g4 + 4 * h;
+                    if (d0 < DK)
+                        store4<IOT>(dqp + d0, acc[(size_t)(dt * 16 + 4 * g4) * 64], acc[(size_t)(dt * 16 + 4 * g4 + 1) * 64],
+                                    acc[(size_t)(dt * 16 + 4 * g4 + 2) * 64], acc[(size_t)(dt * 16 + 4 * g4 + 3) * 64]);
+                }
+        }
+        IOT *dkp = (IOT *)a.dk_.ptr + b * a.dk_.sb + hh * a.dk_.sh;
+        const float *kacc = dkacc + ((size_t)w * DT * 16) * 64 + lane;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 32 * dt + r;
+            if (d < DK) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int j = 32 * w + tile_row(g, h);
+                    if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, kacc[(size_t)(dt * 16 + g) * 64]);
+                }
+            }
+        }
+    }
+}
+
+// sum the per-workgroup dW partials: out[idx] = sum_bh dwp[bh][idx]   (deterministic order)
+__global__ void ew_fused_dw_reduce_kernel(MopkEdgewiseArgs a, BwdWs W, int nwg) {
+    const int nO = 4 * a.r, C = 2 * a.V + 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * nO * (C + 1)) return;
+    float s = 0.f;
+    for (int g = 0; g < nwg; ++g) s += ((const float *)(W.base + (size_t)g * W.stride + W.oDW))[idx];
+    const int side = idx / (nO * (C + 1)), rem = idx % (nO * (C + 1));
+    const int o = rem / (C + 1), c = rem % (C + 1);
+    if (c < C) (side ? a.dWc : a.dWr)[o * C + c] = s; else (side ? a.dbc : a.dbr)[o] = s;
+}
+
+// ------------------------------------------------------------------ host side
+int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
+static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
+
+template <int NT, int DK>
+static size_t bwd_ws_bytes_t(const MopkEdgewiseArgs *a) {
+    return BwdCfg<NT, DK>::carve(nullptr, a->V).stride * (size_t)a->B * a->H + 256;
+}
+template <int NT, int DK>
+static int launch_bwd(const MopkEdgewiseArgs *a, hipStream_t st) {
+    using Cfg = BwdCfg<NT, DK>;
+    const int lds = Cfg::lds_bytes(a->V);
+    if (lds > 160 * 1024 || 2 * a->V + 2 > 18) return MOPK_ERR_UNSUPPORTED;
+    const BwdWs W = Cfg::carve(a->workspace, a->V);
+    const dim3 grid(a->B * a->H), block(NT * 64);
+    if (a->io_dtype == MOPK_BF16) {
+        auto kfn = ew_fused_bwd_kernel<NT, DK, unsigned short>;
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);
+    } else {
+        auto kfn = ew_fused_bwd_kernel<NT, DK, float>;
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);
+    }
+    MOPK_CHECK_LAUNCH();
+    const int nout = 2 * 4 * a->r * (2 * a->V + 3);
+    hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3((nout + 63) / 64), dim3(64), 0, st, *a, W, a->B * a->H);
+    MOPK_CHECK_LAUNCH();
+    return MOPK_OK;
+}
+
+#define MOPK_BWD_DISPATCH(FN, ...)                                                   \
+    switch (pick_nt_b(a->N)) {                                                       \
+        case 1: switch (a->dk) { case 16: return FN<1, 16>(__VA_ARGS__); case 32: return FN<1, 32>(__VA_ARGS__); default: return FN<1, 64>(__VA_ARGS__); } \
+        case 2: switch (a->dk) { case 16: return FN<2, 16>(__VA_ARGS__); case 32: return FN<2, 32>(__VA_ARGS__); default: return FN<2, 64>(__VA_ARGS__); } \
+        case 4: switch (a->dk) { case 16: return FN<4, 16>(__VA_ARGS__); case 32: return FN<4, 32>(__VA_ARGS__); default: return FN<4, 64>(__VA_ARGS__); } \
+        default: switch (a->dk) { case 16: return FN<7, 16>(__VA_ARGS__); case 32: return FN<7, 32>(__VA_ARGS__); default: return FN<7, 64>(__VA_ARGS__); } \
+    }
+
+int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {
+    if (!ew_fused_fwd_supported(a)) return 0;
+    if (a->dq.sv != 0 || a->dk_.sv != 0) return 0;
+    return 1;
+}
+size_t ew_fused_bwd_ws_bytes(const MopkEdgewiseArgs *a) {
+    MOPK_BWD_DISPATCH(bwd_ws_bytes_t, a)
+}
+int ew_fused_bwd(const MopkEdgewiseArgs *a, hipStream_t st) {
+    if (!ew_fused_bwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
+    MOPK_BWD_DISPATCH(launch_bwd, a, st)
+}
+
+}  // namespace mopk

@@ -152,11 +152,12 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.chain_logit = f["logit"].data_ptr()
         y = torch.empty(B, N, H, dk, dtype=qkv.dtype, device=dev)
         a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
-        if path == L.PATH_AUTO and not want_bwd and lib.mopk_edgewise_fused_supported(C.byref(a)):
-            a.path = path = L.PATH_FUSED  # forward-only: fused kernel (the fused backward is not built yet)
+        if path == L.PATH_AUTO:   # AUTO: fused gfx950 kernels when they cover the shape, generic otherwise
+            path = L.PATH_FUSED if lib.mopk_edgewise_fused_supported(C.byref(a)) else L.PATH_GENERIC
+        a.path = path
         LAST_PATH["edgewise_fwd"] = path
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
-        ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
+        ws = _bytes(256 if path == L.PATH_FUSED else lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("edgewise_fwd"):
             rc = lib.mopk_edgewise_lowrank_fwd(C.byref(a), _stream())
@@ -200,6 +201,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.dsqk_part, a.dvs0_part, a.dvsL_part = dsqk.data_ptr(), dvs0.data_ptr(), dvsL.data_ptr()
         a.dWr, a.dbr, a.dWc, a.dbc = dWr.data_ptr(), dbr.data_ptr(), dWc.data_ptr(), dbc.data_ptr()
         a.dlogit_part = dlg.data_ptr()
+        LAST_PATH["edgewise_bwd"] = path
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("edgewise_bwd"):
