@@ -1,14 +1,23 @@
-"""Build libmopk.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libmopk.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Every source is compiled to an object in parallel; the two fused-kernel sources are compiled once per
+(NT, DK) instantiation pair (-DMOPK_INST_NT/-DMOPK_INST_DK) plus once as the dispatcher (NT=0).
+"""
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmopk.so")
-SOURCES = ["api.hip", "edgewise_generic.hip", "edgewise_fused.hip", "edgewise_fused_bwd.hip", "attn_generic.hip"]
+PLAIN = ["api.hip", "edgewise_generic.hip", "attn_generic.hip"]
+FUSED = ["edgewise_fused.hip", "edgewise_fused_bwd.hip"]
+NTS, DKS = (1, 2, 4, 7), (16, 32, 64)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:
@@ -18,31 +27,58 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libmopk.so cannot be built")
 
 
-def sources():
-    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+def _jobs():
+    jobs = [(s, [], s.replace(".hip", ".o")) for s in PLAIN]
+    for s in FUSED:
+        stem = s.replace(".hip", "")
+        jobs.append((s, ["-DMOPK_INST_NT=0", "-DMOPK_INST_DK=0"], f"{stem}_disp.o"))
+        for nt in NTS:
+            for dk in DKS:
+                jobs.append((s, [f"-DMOPK_INST_NT={nt}", f"-DMOPK_INST_DK={dk}"], f"{stem}_nt{nt}_dk{dk}.o"))
+    return jobs
+
+
+def _deps_mtime() -> float:
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mopk.h"),
+                                                               os.path.abspath(__file__)]
+    return max(os.path.getmtime(d) for d in deps)
 
 
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mopk.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not os.path.exists(LIB) or os.path.getmtime(LIB) < _deps_mtime()
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+def build_lib(force: bool = False, verbose: bool = False, workers: int = 8) -> str:
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result", "-o", LIB + ".tmp"] + sources()
-    if verbose:
-        print(" ".join(cmd))
+    cc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    newest = _deps_mtime()
+
+    def compile_one(job):
+        src, defs, obj = job
+        out = os.path.join(OBJ, obj)
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+            return out
+        cmd = [cc] + FLAGS + defs + ["-c", "-o", out, os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src} {defs}:\n" + r.stdout + r.stderr)
+        return out
+
+    # biggest kernels first so the pool stays busy
+    jobs = sorted(_jobs(), key=lambda j: (-("nt7" in j[2]) * 2 - ("nt4" in j[2]), j[2]))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    print(build_lib(force=True, verbose=False))

@@ -446,10 +446,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 }
 
 // ------------------------------------------------------------------ host side
-static int pick_nt(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
-
-template <int NT, int DK>
-static int launch_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
+// The file is compiled once per (NT, DK) with -DMOPK_INST_NT / -DMOPK_INST_DK (one translation unit
+// per instantiation pair keeps the build parallel) and once with MOPK_INST_NT=0 for the dispatcher.
+#define MOPK_CAT_(a, b, c, d) a##b##c##d
+#define MOPK_CAT(a, b, c, d) MOPK_CAT_(a, b, c, d)
+#if MOPK_INST_NT != 0
+int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st) {
+    constexpr int NT = MOPK_INST_NT, DK = MOPK_INST_DK;
     const int lds = FusedCfg<NT, DK>::lds_bytes(a->V);
     if (lds > 160 * 1024) return MOPK_ERR_UNSUPPORTED;
     const dim3 grid(a->B * a->H), block(NT * 64);
@@ -465,7 +468,12 @@ static int launch_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
 }
-
+#else
+#define MOPK_DECL(NT_, DK_) int ew_fused_fwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st);
+MOPK_DECL(1, 16) MOPK_DECL(1, 32) MOPK_DECL(1, 64) MOPK_DECL(2, 16) MOPK_DECL(2, 32) MOPK_DECL(2, 64)
+MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
+#undef MOPK_DECL
+static int pick_nt(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
@@ -485,21 +493,21 @@ int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
 
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     if (!ew_fused_fwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
-    const int nt = pick_nt(a->N);
-#define MOPK_DK(NT_)                                                  \
-    switch (a->dk) {                                                  \
-        case 16: return launch_fwd<NT_, 16>(a, st);                   \
-        case 32: return launch_fwd<NT_, 32>(a, st);                   \
-        default: return launch_fwd<NT_, 64>(a, st);                   \
+#define MOPK_DK(NT_)                                                         \
+    switch (a->dk) {                                                         \
+        case 16: return ew_fused_fwd_nt##NT_##_dk16(a, st);                  \
+        case 32: return ew_fused_fwd_nt##NT_##_dk32(a, st);                  \
+        default: return ew_fused_fwd_nt##NT_##_dk64(a, st);                  \
     }
-    switch (nt) {
+    switch (pick_nt(a->N)) {
         case 1: MOPK_DK(1)
         case 2: MOPK_DK(2)
         case 4: MOPK_DK(4)
         default: MOPK_DK(7)
     }
-    return MOPK_ERR_UNSUPPORTED;
 #undef MOPK_DK
+    return MOPK_ERR_UNSUPPORTED;
 }
+#endif
 
 }  // namespace mopk

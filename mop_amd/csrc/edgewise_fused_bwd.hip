@@ -20,9 +20,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct BwdWs {
     unsigned char *base;     // workspace base
     size_t stride;           // bytes per workgroup
-    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW;
+    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW, oDA;
 };
-enum { S_CF = 0, S_CB, S_C0, S_C1, S_C2, S_C3, S_L, S_DP, S_DL };   // S_DL .. S_DL+V-1
+enum { S_CF = 0, S_CB, S_C0, S_C1, S_C2, S_C3, S_L, S_DP, S_DS, S_DL };   // S_DL .. S_DL+V-1
 
 template <int NT, int DK>
 struct BwdCfg {
@@ -47,6 +47,7 @@ struct BwdCfg {
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
         w.oAcc = o; o += a256((size_t)2 * NT * DT * 16 * 64 * 4);
         w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
+        w.oDA = o; o += a256((size_t)NT * NT * 16 * 64 * 4);     // fp32 dA slab of every wave
         w.stride = a256(o);
         return w;
     }
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
     float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)NT * DT * 16 * 64;
     float *dwp = (float *)(ws + W.oDW);
+    float *dapark = (float *)(ws + W.oDA) + (size_t)w * NT * 16 * 64 + lane;   // [(t*16+g)][lane]
     auto slot = [&](int s) -> u32x4 * { return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane; };
     // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
 
@@ -897,56 +899,68 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     for (int t = 0; t < NT; ++t) X[t] += unpack_tile_bf(Dl[t][0], Dl[t][1]);
                 }
             }
-            // ---- softmax backward + direct + mean terms -> dS_v^T (in place)
+            // ---- softmax backward + direct + mean terms -> dS_v^T.  The dA slab is parked in L2 (fp32) so the
+            //      tile loops below stay rolled with the whole register file free (keeping it in VGPRs made
+            //      hipcc spill ~8000 registers around the rolled loops).
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) dapark[(size_t)(t * 16 + g) * 64] = X[t][g];
             {
                 const float smx = stats[(v * NP + qi) * 2], sinv = stats[(v * NP + qi) * 2 + 1];
-                bf16x8 qe[KS], qe0[KS];
+                bf16x8 qe[KS];
                 make_frag(qe, qrow, sqk + v * DK);
                 float dot = 0.f;
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x16 A = a_tile(qe, t, smx, sinv);
-                    const f32x16 dA = tile_get<NT>(X, t);
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dA[g], dot);
+                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dapark[(size_t)(t * 16 + g) * 64], dot);
                 }
                 dot += __shfl_xor(dot, 32, 64);
-                if (v != 0) make_frag(qe0, qrow, sqk);
                 const float drs = dmean[v * NP + qi];
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
-                    f32x16 Sv = s_tile(qe, t);
+                    const f32x16 Sv = s_tile(qe, t);
                     f32x16 pi;
                     {
                         const u32x4 *p = slot(S_L);
-                        const f32x16 L = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);
+                        pi = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);        // L = lse - S0
                         if (v != 0) {
+                            bf16x8 qe0[KS];
+                            make_frag(qe0, qrow, sqk);
                             const f32x16 S0 = s_tile(qe0, t);
 #pragma unroll
-                            for (int g = 0; g < 16; ++g) pi[g] = __expf(Sv[g] - S0[g] - L[g]);
+                            for (int g = 0; g < 16; ++g) pi[g] = __expf(Sv[g] - S0[g] - pi[g]);
                         } else {
 #pragma unroll
-                            for (int g = 0; g < 16; ++g) pi[g] = __expf(-L[g]);
+                            for (int g = 0; g < 16; ++g) pi[g] = __expf(-pi[g]);
                         }
                     }
-                    const u32x4 *pc = slot(v == 0 ? S_C0 : S_C1);
-                    const u32x4 *p2 = slot(S_C2);
-                    const f32x16 cd = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
-                    const f32x16 c2 = unpack_tile_bf(as_b8(p2[(2 * t) * 64]), as_b8(p2[(2 * t + 1) * 64]));
-                    const f32x16 dA = tile_get<NT>(X, t);
+                    {
+                        const u32x4 *p2 = slot(S_C2);
+                        const f32x16 c2 = unpack_tile_bf(as_b8(p2[(2 * t) * 64]), as_b8(p2[(2 * t + 1) * 64]));
+                        const u32x4 *pc = slot(v == 0 ? S_C0 : S_C1);
+                        const f32x16 cd = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) pi[g] = fmaf(c2[g], pi[g], cd[g]);
+                    }
                     f32x16 dS;
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * t + tile_row(g, h);
                         const float A = __expf(Sv[g] - smx) * sinv;
-                        dS[g] = j < N ? A * (dA[g] - dot) + cd[g] + c2[g] * pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
+                        dS[g] = j < N ? A * (dapark[(size_t)(t * 16 + g) * 64] - dot) + pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
                     }
-                    tile_set<NT>(X, t, dS);
+                    bf16x8 lo, hi;
+                    pack_tile_bf(lo, hi, dS);
+                    u32x4 *ps = slot(S_DS);
+                    ps[(2 * t) * 64] = as_u4(lo); ps[(2 * t + 1) * 64] = as_u4(hi);
                 }
             }
             // ---- dQe_v^T = K^T dS^T ; dq += sqk_v * dQe_v ; dsqk_v = sum_i q * dQe_v
             bf16x8 Sp[NT][2];
-            pack_all(Sp, X);
+            slot_ld(S_DS, Sp);
             {
                 f32x16 dq[DT];
                 gemm_small(dq, KT, Sp);
@@ -1057,28 +1071,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     }
 }
 
-// sum the per-workgroup dW partials: out[idx] = sum_bh dwp[bh][idx]   (deterministic order)
-__global__ void ew_fused_dw_reduce_kernel(MopkEdgewiseArgs a, BwdWs W, int nwg) {
-    const int nO = 4 * a.r, C = 2 * a.V + 2;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * nO * (C + 1)) return;
-    float s = 0.f;
-    for (int g = 0; g < nwg; ++g) s += ((const float *)(W.base + (size_t)g * W.stride + W.oDW))[idx];
-    const int side = idx / (nO * (C + 1)), rem = idx % (nO * (C + 1));
-    const int o = rem / (C + 1), c = rem % (C + 1);
-    if (c < C) (side ? a.dWc : a.dWr)[o * C + c] = s; else (side ? a.dbc : a.dbr)[o] = s;
+// ------------------------------------------------------------------ host side (see edgewise_fused.hip)
+#define MOPK_CAT_(a, b, c, d) a##b##c##d
+#define MOPK_CAT(a, b, c, d) MOPK_CAT_(a, b, c, d)
+#if MOPK_INST_NT != 0
+size_t MOPK_CAT(ew_fused_bwd_ws_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a) {
+    return BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::carve(nullptr, a->V).stride * (size_t)a->B * a->H + 256;
 }
-
-// ------------------------------------------------------------------ host side
-int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
-static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
-
-template <int NT, int DK>
-static size_t bwd_ws_bytes_t(const MopkEdgewiseArgs *a) {
-    return BwdCfg<NT, DK>::carve(nullptr, a->V).stride * (size_t)a->B * a->H + 256;
-}
-template <int NT, int DK>
-static int launch_bwd(const MopkEdgewiseArgs *a, hipStream_t st) {
+void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, hipStream_t st);
+int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st) {
+    constexpr int NT = MOPK_INST_NT, DK = MOPK_INST_DK;
     using Cfg = BwdCfg<NT, DK>;
     const int lds = Cfg::lds_bytes(a->V);
     if (lds > 160 * 1024 || 2 * a->V + 2 > 18) return MOPK_ERR_UNSUPPORTED;
@@ -1094,31 +1096,58 @@ static int launch_bwd(const MopkEdgewiseArgs *a, hipStream_t st) {
         hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);
     }
     MOPK_CHECK_LAUNCH();
-    const int nout = 2 * 4 * a->r * (2 * a->V + 3);
-    hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3((nout + 63) / 64), dim3(64), 0, st, *a, W, a->B * a->H);
+    ew_fused_dw_reduce(a, W, st);
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
 }
+#else
+// sum the per-workgroup dW partials: out[idx] = sum_bh dwp[bh][idx]   (deterministic order)
+__global__ void ew_fused_dw_reduce_kernel(MopkEdgewiseArgs a, BwdWs W, int nwg) {
+    // one block per output; 256 threads stride over the workgroups, fixed-shape tree reduction
+    __shared__ float red[256];
+    const int nO = 4 * a.r, C = 2 * a.V + 2;
+    const int idx = blockIdx.x;
+    float s = 0.f;
+    for (int g = threadIdx.x; g < nwg; g += 256) s += ((const float *)(W.base + (size_t)g * W.stride + W.oDW))[idx];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x != 0) return;
+    s = red[0];
+    const int side = idx / (nO * (C + 1)), rem = idx % (nO * (C + 1));
+    const int o = rem / (C + 1), c = rem % (C + 1);
+    if (c < C) (side ? a.dWc : a.dWr)[o * C + c] = s; else (side ? a.dbc : a.dbr)[o] = s;
+}
 
-#define MOPK_BWD_DISPATCH(FN, ...)                                                   \
+void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, hipStream_t st) {
+    const int nout = 2 * 4 * a->r * (2 * a->V + 3);
+    hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3(nout), dim3(256), 0, st, *a, W, a->B * a->H);
+}
+int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
+#define MOPK_DECL(NT_, DK_) int ew_fused_bwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st); \
+                            size_t ew_fused_bwd_ws_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a);
+MOPK_DECL(1, 16) MOPK_DECL(1, 32) MOPK_DECL(1, 64) MOPK_DECL(2, 16) MOPK_DECL(2, 32) MOPK_DECL(2, 64)
+MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
+#undef MOPK_DECL
+static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
+#define MOPK_BWD_DISPATCH(PFX, ...)                                                   \
     switch (pick_nt_b(a->N)) {                                                       \
-        case 1: switch (a->dk) { case 16: return FN<1, 16>(__VA_ARGS__); case 32: return FN<1, 32>(__VA_ARGS__); default: return FN<1, 64>(__VA_ARGS__); } \
-        case 2: switch (a->dk) { case 16: return FN<2, 16>(__VA_ARGS__); case 32: return FN<2, 32>(__VA_ARGS__); default: return FN<2, 64>(__VA_ARGS__); } \
-        case 4: switch (a->dk) { case 16: return FN<4, 16>(__VA_ARGS__); case 32: return FN<4, 32>(__VA_ARGS__); default: return FN<4, 64>(__VA_ARGS__); } \
-        default: switch (a->dk) { case 16: return FN<7, 16>(__VA_ARGS__); case 32: return FN<7, 32>(__VA_ARGS__); default: return FN<7, 64>(__VA_ARGS__); } \
+        case 1: switch (a->dk) { case 16: return PFX##nt1_dk16(__VA_ARGS__); case 32: return PFX##nt1_dk32(__VA_ARGS__); default: return PFX##nt1_dk64(__VA_ARGS__); } \
+        case 2: switch (a->dk) { case 16: return PFX##nt2_dk16(__VA_ARGS__); case 32: return PFX##nt2_dk32(__VA_ARGS__); default: return PFX##nt2_dk64(__VA_ARGS__); } \
+        case 4: switch (a->dk) { case 16: return PFX##nt4_dk16(__VA_ARGS__); case 32: return PFX##nt4_dk32(__VA_ARGS__); default: return PFX##nt4_dk64(__VA_ARGS__); } \
+        default: switch (a->dk) { case 16: return PFX##nt7_dk16(__VA_ARGS__); case 32: return PFX##nt7_dk32(__VA_ARGS__); default: return PFX##nt7_dk64(__VA_ARGS__); } \
     }
-
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {
     if (!ew_fused_fwd_supported(a)) return 0;
     if (a->dq.sv != 0 || a->dk_.sv != 0) return 0;
     return 1;
 }
 size_t ew_fused_bwd_ws_bytes(const MopkEdgewiseArgs *a) {
-    MOPK_BWD_DISPATCH(bwd_ws_bytes_t, a)
+    MOPK_BWD_DISPATCH(ew_fused_bwd_ws_, a)
 }
 int ew_fused_bwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     if (!ew_fused_bwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
-    MOPK_BWD_DISPATCH(launch_bwd, a, st)
+    MOPK_BWD_DISPATCH(ew_fused_bwd_, a, st)
 }
+#endif
 
 }  // namespace mopk

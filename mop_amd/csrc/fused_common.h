@@ -72,13 +72,21 @@ __device__ __forceinline__ void pack_slab(bf16x8 (&Xp)[NT][2], const f32x16 (&X)
 // overlap the tiles' live ranges and spill).
 template <int NT> __device__ __forceinline__ f32x16 tile_get(const f32x16 (&X)[NT], int t) {
     f32x16 r = X[0];
-#pragma unroll
-    for (int k = 1; k < NT; ++k) if (t == k) r = X[k];
+    switch (t) {   // t is wave-uniform: scalar branches, no per-lane select chains
+#define MOPK_TG(K_) case K_: if (K_ < NT) r = X[K_ < NT ? K_ : 0]; break;
+        MOPK_TG(1) MOPK_TG(2) MOPK_TG(3) MOPK_TG(4) MOPK_TG(5) MOPK_TG(6) MOPK_TG(7)
+#undef MOPK_TG
+        default: break;
+    }
     return r;
 }
 template <int NT> __device__ __forceinline__ void tile_set(f32x16 (&X)[NT], int t, const f32x16 &v) {
-#pragma unroll
-    for (int k = 0; k < NT; ++k) if (t == k) X[k] = v;
+    switch (t) {
+#define MOPK_TS(K_) case K_: if (K_ < NT) X[K_ < NT ? K_ : 0] = v; break;
+        MOPK_TS(0) MOPK_TS(1) MOPK_TS(2) MOPK_TS(3) MOPK_TS(4) MOPK_TS(5) MOPK_TS(6) MOPK_TS(7)
+#undef MOPK_TS
+        default: break;
+    }
 }
 
 }  // namespace mopk
