@@ -18,6 +18,8 @@ PLAIN = ["api.hip", "edgewise_generic.hip", "attn_generic.hip"]
 FUSED = ["edgewise_fused.hip", "edgewise_fused_bwd.hip"]
 NTS, DKS = (1, 2, 4, 7), (16, 32, 64)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("MOPK_STAMPS"):  # diagnostic build: s_memtime stamps per phase (never benchmark this build)
+    FLAGS.append("-DMOPK_STAMPS")
 
 
 def _hipcc() -> str:

@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct BwdWs {
     unsigned char *base;     // workspace base
     size_t stride;           // bytes per workgroup
-    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW, oDA;
+    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW, oDA, oStamp;
 };
 enum { S_CF = 0, S_CB, S_C0, S_C1, S_C2, S_C3, S_L, S_DP, S_DS, S_DL };   // S_DL .. S_DL+V-1
 
@@ -48,6 +48,7 @@ struct BwdCfg {
         w.oAcc = o; o += a256((size_t)2 * NT * DT * 16 * 64 * 4);
         w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
         w.oDA = o; o += a256((size_t)NT * NT * 16 * 64 * 4);     // fp32 dA slab of every wave
+        w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds)
         w.stride = a256(o);
         return w;
     }
@@ -108,11 +109,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     float *redbuf = colpart + imax(NT * NP + 2 * a.V * NP, (2 * a.V + 4) * NP);   // [2][NT][DK]
     float *misc = redbuf + 2 * NT * DK;                               // wsig, ...
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, w = tid >> 6;
+    int lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int N = a.N, V = a.V, H = a.H, RK = a.r;
-    const int b = blockIdx.x / H, hh = blockIdx.x % H;
-    const int qi = 32 * w + r;
-    const bool qok = qi < N;
+    int qi = 32 * w + r;
+    bool qok = qi < N;
+    // REFRESH(): make the lane id opaque so address arithmetic derived from it is recomputed per phase instead of
+    // being hoisted to the kernel prologue and spilled (hipcc LICM + rematerialisation failure: ~1000 spills)
+#define REFRESH() do { asm volatile("" : "+v"(lane)); r = lane & 31; h = lane >> 5; qi = 32 * w + r; qok = qi < N; } while (0)
     const float invN = 1.f / (float)N;
     const int C = 2 * V + 2;
 
@@ -124,13 +128,24 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
     float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)NT * DT * 16 * 64;
     float *dwp = (float *)(ws + W.oDW);
-    float *dapark = (float *)(ws + W.oDA) + (size_t)w * NT * 16 * 64 + lane;   // [(t*16+g)][lane]
     auto slot = [&](int s) -> u32x4 * { return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane; };
     // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
 
+#ifdef MOPK_STAMPS
+    unsigned long long *stamps = (unsigned long long *)(ws + W.oStamp);
+    int stamp_i = 0;
+#define STAMP() do { if (blockIdx.x == 0 && tid == 0 && stamp_i < 60) stamps[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#else
+#define STAMP() do { } while (0)
+#endif
+    // persistent workgroup: scratch is indexed by blockIdx (stays hot in L2 / Infinity Cache), (b,h) pairs are strided
+    for (int bh = blockIdx.x; bh < a.B * H; bh += gridDim.x) {
+    const int b = bh / H, hh = bh % H;
+    const bool first_pass = bh == (int)blockIdx.x;
+    const float *ych = (const float *)a.saved + (size_t)bh * N * DK;   // w * y_chain from the fused forward
+    STAMP();
     const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
     const IOT *dyrow = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)qi * a.dy.sn;
-    const float *ych = (const float *)a.saved + (size_t)blockIdx.x * N * DK;   // w * y_chain from the fused forward
 
     // ================= P0: stage operands =================
     {
@@ -219,10 +234,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
     };
     auto s_tile = [&](const bf16x8 (&qe)[KS], int t) -> f32x16 {                   // S^T tile [key, query] from K in LDS
+        const unsigned short *kbase = Ksm + r * LDK + 8 * h;   // lane base + compile-time offsets
         f32x16 acc = zero16();
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 af = *(const bf16x8 *)&Ksm[(32 * t + r) * LDK + 16 * s + 8 * h];
+            const bf16x8 af = *(const bf16x8 *)&kbase[(32 * t) * LDK + 16 * s];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qe[s], acc, 0, 0, 0);
         }
         return acc;
@@ -231,7 +247,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         f32x16 acc = zero16();
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 af = *(const bf16x8 *)&Arows[(32 * t + r) * DK + 16 * s + 8 * h];
+            const bf16x8 af = *(const bf16x8 *)&(Arows + r * DK + 8 * h)[(32 * t) * DK + 16 * s];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, fr[s], acc, 0, 0, 0);
         }
         return acc;
@@ -250,9 +266,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sm = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 16; ++g) { const float e = __expf(X[t][g] - mx); X[t][g] = e; sm += e; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         sm += __shfl_xor(sm, 32, 64);
         const float inv = 1.f / sm;
 #pragma unroll
@@ -267,45 +286,52 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     };
     // form (i): dst[j][perm(i)] = X^T slab (A operand for products contracting over QUERIES)
     auto store_i = [&](unsigned short *dst, const f32x16 (&X)[NT]) {
-        const int col = 32 * w + 16 * (r >> 4) + kperm16(r & 15);
+        unsigned short *base = dst + (4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dst[(32 * t + tile_row(g, h)) * LDA + col] = f2bf(X[t][g]);
+            for (int g = 0; g < 16; ++g) base[(32 * t + (g & 3) + 8 * (g >> 2)) * LDA] = f2bf(X[t][g]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto store_i_tile = [&](unsigned short *dst, int t, bf16x8 lo, bf16x8 hi) {
-        const int col = 32 * w + 16 * (r >> 4) + kperm16(r & 15);
+        unsigned short *base = dst + (32 * t + 4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            dst[(32 * t + tile_row(g, h)) * LDA + col] = (unsigned short)lo[g];
-            dst[(32 * t + tile_row(8 + g, h)) * LDA + col] = (unsigned short)hi[g];
+            base[((g & 3) + 8 * (g >> 2)) * LDA] = (unsigned short)lo[g];
+            base[((g & 3) + 8 * (g >> 2) + 16) * LDA] = (unsigned short)hi[g];
         }
     };
     // form (ii): dst[i][perm(j)] = slab rows (A operand for products contracting over KEYS)
     auto store_ii = [&](unsigned short *dst, const f32x16 (&X)[NT]) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 // regs 4g4..4g4+3 <-> keys 32t + 8g4 + 4h + {0..3}; permuted position keeps the low 2 bits
-                const int j0 = 32 * t + 8 * g4 + 4 * h;
-                const int col = (j0 & ~15) + kperm16(j0 & 15);
-                *(uint2 *)&dst[qi * LDA + col] = make_uint2(pack_bf16(X[t][4 * g4], X[t][4 * g4 + 1]), pack_bf16(X[t][4 * g4 + 2], X[t][4 * g4 + 3]));
+                // permuted position of key 32t + 8g4 + 4h: 16-group base + (8h + 4(g4&1))
+                *(uint2 *)&(dst + qi * LDA + 8 * h)[32 * t + 16 * (g4 >> 1) + 4 * (g4 & 1)] = make_uint2(pack_bf16(X[t][4 * g4], X[t][4 * g4 + 1]), pack_bf16(X[t][4 * g4 + 2], X[t][4 * g4 + 3]));
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto gemm_lds_reg = [&](f32x16 (&Xn)[NT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
 #pragma unroll
         for (int to = 0; to < NT; ++to) {
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 acc = zero16();
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * to + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
                 }
             Xn[to] = acc;
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
     // acc[to] += sum_i Am[j][i] * Bm[k][i]   (A rows j from LDS, B rows k = this lane's query from a global AT-format image)
     auto gemm_lds_glob = [&](f32x16 (&acc)[NT], const unsigned short *Am, const unsigned short *Bm) {
@@ -314,10 +340,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 bfr = *(const bf16x8 *)&brow[32 * t + 16 * s + 8 * h];
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 bfr = *(const bf16x8 *)&(brow + 8 * h)[32 * t + 16 * s];
 #pragma unroll
                 for (int to = 0; to < NT; ++to) {
-                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * to + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
                     acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[to], 0, 0, 0);
                 }
             }
@@ -326,12 +353,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     auto gemm_small = [&](f32x16 (&out)[DT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 acc = zero16();
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
                 }
             out[dt] = acc;
@@ -345,24 +373,41 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 af = *(const bf16x8 *)&Am[(32 * w + r) * LDA + 32 * t + 16 * s + 8 * h];
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 af = *(const bf16x8 *)&(Am + (32 * w + r) * LDA + 8 * h)[32 * t + 16 * s];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 bfr = *(const bf16x8 *)&Bm[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    const bf16x8 bfr = *(const bf16x8 *)&(Bm + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
                     out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, out[dt], 0, 0, 0);
                 }
             }
+    };
+    // AT image of a packed slab with a rolled tile loop (uniform switch picks the registers)
+    auto store_i_packed = [&](unsigned short *dst, const bf16x8 (&Xp)[NT][2]) {
+#pragma nounroll
+        for (int t = 0; t < NT; ++t) {
+            bf16x8 lo = Xp[0][0], hi = Xp[0][1];
+            switch (t) {
+#define MOPK_GP(K_) case K_: if (K_ < NT) { lo = Xp[K_ < NT ? K_ : 0][0]; hi = Xp[K_ < NT ? K_ : 0][1]; } break;
+                MOPK_GP(1) MOPK_GP(2) MOPK_GP(3) MOPK_GP(4) MOPK_GP(5) MOPK_GP(6)
+#undef MOPK_GP
+                default: break;
+            }
+            store_i_tile(dst, t, lo, hi);
+        }
     };
     auto pack_all = [&](bf16x8 (&Xp)[NT][2], const f32x16 (&X)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) pack_tile_bf(Xp[t][0], Xp[t][1], X[t]);
     };
     auto slot_st = [&](int s, const bf16x8 (&Xp)[NT][2]) {
+        __builtin_amdgcn_sched_barrier(0);
         u32x4 *p = slot(s);
 #pragma unroll
         for (int t = 0; t < NT; ++t) { p[(2 * t) * 64] = as_u4(Xp[t][0]); p[(2 * t + 1) * 64] = as_u4(Xp[t][1]); }
     };
     auto slot_ld = [&](int s, bf16x8 (&Xp)[NT][2]) {
+        __builtin_amdgcn_sched_barrier(0);
         const u32x4 *p = slot(s);
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(p[(2 * t) * 64]); Xp[t][1] = as_b8(p[(2 * t + 1) * 64]); }
@@ -371,6 +416,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         float rs = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
             float c[16];
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -395,17 +441,22 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         rs += __shfl_xor(rs, 32, 64);
         if (h == 0) rout[qi] = rs * invN;
     };
-    // forward chain recompute; every prefix product (m = 0..V-2) is written to Pg[m] in AT format
+    // copy the AT image staged in R to a global image with coalesced 16-byte accesses (all threads)
+    auto export_R = [&](unsigned short *dst) {
+        const u32x4 *src = (const u32x4 *)R;
+        u32x4 *out = (u32x4 *)dst;
+        for (int c = tid; c < NP * LDA / 8; c += NTH) out[c] = src[c];
+    };
+    // forward chain recompute; every prefix product T_m (m = 0..V-2) is staged in R (AT format) and copied to Pg[m]
     auto run_chain = [&](f32x16 (&X)[NT], bool forward, unsigned short *Pg) {
         bf16x8 Xp[NT][2];
         a_slab(X, forward ? 0 : V - 1);
         for (int m = 1; m < V; ++m) {
+            __syncthreads();                  // R free (previous GEMM / export readers done)
+            store_i(R, X);                    // T_{m-1}^T image
+            __syncthreads();
+            export_R(Pg + (size_t)(m - 1) * NP * LDA);
             pack_all(Xp, X);
-            {
-                unsigned short *dst = Pg + (size_t)(m - 1) * NP * LDA;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) store_i_tile(dst, t, Xp[t][0], Xp[t][1]);
-            }
             a_slab(X, forward ? m : V - 1 - m);
             __syncthreads();
             store_i(R, X);
@@ -415,6 +466,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     };
 
     f32x16 X[NT];
+    STAMP();
+    REFRESH();
     // ================= P1/P2: forward chains (recompute) =================
     __syncthreads();                     // P0 global images + LDS complete
     run_chain(X, false, Ug);
@@ -441,6 +494,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     __syncthreads();
     if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
     __syncthreads();
+    STAMP();
+    REFRESH();
     // ================= P3: gate vectors =================
     if (tid < NP) {
         const int j = tid;
@@ -487,6 +542,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
     }
     __syncthreads();
+    STAMP();
+    REFRESH();
     // ================= P4: mix recompute -> Smix (crp), L parked =================
     const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
     auto gate_tile = [&](int t, int g4) -> f32x16 {
@@ -580,6 +637,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int q = 0; q < 8; ++q) { p[2 * q] = __expf(h2_lo(cw[q]) - mxrow) * invl; p[2 * q + 1] = __expf(h2_hi(cw[q]) - mxrow) * invl; }
         return p;
     };
+    STAMP();
+    REFRESH();
     // ================= P5: delta_i = sum_j P dP =================
     bf16x8 dyf[KS];
     make_frag(dyf, dyrow, nullptr);
@@ -594,6 +653,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int g = 0; g < 16; ++g) delta = fmaf(P[g], dP[g], delta);
     }
     delta += __shfl_xor(delta, 32, 64);
+    STAMP();
+    REFRESH();
     // ================= P6: mix backward =================
     f32x16 daacc = zero16();
     unsigned short *tb = tbuf + w * 32 * 40;
@@ -706,6 +767,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         dbv[c] = s;
     }
     __syncthreads();
+    STAMP();
+    REFRESH();
     // ================= P7: gradients of the gate-head inputs / weights =================
     {
         // dW partials first (they read rS/cS which dmean is about to overwrite)
@@ -724,7 +787,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
                 s = fmaf(g[n], f, s);
             }
-            dwp[idx] = s;
+            dwp[idx] = first_pass ? s : dwp[idx] + s;
         }
         __syncthreads();
         if (tid < NP) {
@@ -747,6 +810,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
         __syncthreads();
     }
+    STAMP();
+    REFRESH();
     // ================= P8: dv0 = P^T dy, dvL = w C->^T dy =================
     {
 #pragma nounroll
@@ -765,8 +830,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         {
             bf16x8 Xp[NT][2];
             slot_ld(S_CF, Xp);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) store_i_tile(R, t, Xp[t][0], Xp[t][1]);
+            store_i_packed(R, Xp);
         }
         __syncthreads();
         gemm_rows_glob(gL, R, DYT);                    // (C->^T dy)[j][d]
@@ -817,6 +881,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         __syncthreads();
         if (tid == 0) { float s = 0.f; for (int ww = 0; ww < NT; ++ww) s += misc[4 + ww]; a.dlogit_part[(int64_t)b * H + hh] = s * (1.f - wv); }
     }
+    STAMP();
+    REFRESH();
     // ================= P9: <- chain backward: D'_m slabs parked in S_DL+m =================
     {
         const float drl = dmean[(2 * V + 2) * NP + qi];
@@ -847,6 +913,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         pack_all(Dp, X);
         slot_st(S_DL, Dp);
     }
+    STAMP();
+    REFRESH();
     // ================= P10: -> chain backward with per-view totals =================
     {
         // dC->^T slab
@@ -871,11 +939,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         pack_all(Dp, X);
         for (int v = V - 1; v >= 0; --v) {
             slot_st(S_DP, Dp);                         // park D_v (B operand of the D-chain step below)
+            REFRESH();
             // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index)
             if (v >= 1) {
                 __syncthreads();
-#pragma unroll
-                for (int t = 0; t < NT; ++t) store_i_tile(R, t, Dp[t][0], Dp[t][1]);
+                store_i_packed(R, Dp);
                 __syncthreads();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) X[t] = zero16();
@@ -890,8 +958,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 slot_ld(S_DL + mp, Dl);
                 if (mp >= 1) {
                     __syncthreads();
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) store_i_tile(R, t, Dl[t][0], Dl[t][1]);
+                    store_i_packed(R, Dl);
                     __syncthreads();
                     gemm_lds_glob(X, R, Ug + (size_t)(mp - 1) * NP * LDA);
                 } else {
@@ -899,13 +966,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     for (int t = 0; t < NT; ++t) X[t] += unpack_tile_bf(Dl[t][0], Dl[t][1]);
                 }
             }
-            // ---- softmax backward + direct + mean terms -> dS_v^T.  The dA slab is parked in L2 (fp32) so the
-            //      tile loops below stay rolled with the whole register file free (keeping it in VGPRs made
-            //      hipcc spill ~8000 registers around the rolled loops).
+            if (v == V - 1) STAMP();
+            REFRESH();
+            // ---- softmax backward + direct + mean terms -> dS_v^T.  The dA slab is parked (bf16) in this wave's
+            //      private 14 KB of the R region, which is idle between the dA GEMMs and the dS^T image: the tile
+            //      loops below stay rolled with the whole register file free (keeping dA in VGPRs made hipcc
+            //      spill ~8000 registers around the rolled loops).
+            __syncthreads();                               // every wave is done reading the D images in R
+            unsigned short *dapark = R + (size_t)w * NT * 16 * 64 + lane;    // [(t*16+g)][lane]
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) dapark[(size_t)(t * 16 + g) * 64] = X[t][g];
+                for (int g = 0; g < 16; ++g) dapark[(t * 16 + g) * 64] = f2bf(X[t][g]);
+            bf16x8 Sp[NT][2];
             {
                 const float smx = stats[(v * NP + qi) * 2], sinv = stats[(v * NP + qi) * 2 + 1];
                 bf16x8 qe[KS];
@@ -915,7 +988,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 for (int t = 0; t < NT; ++t) {
                     const f32x16 A = a_tile(qe, t, smx, sinv);
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dapark[(size_t)(t * 16 + g) * 64], dot);
+                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], bf2f(dapark[(t * 16 + g) * 64]), dot);
                 }
                 dot += __shfl_xor(dot, 32, 64);
                 const float drs = dmean[v * NP + qi];
@@ -950,17 +1023,21 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * t + tile_row(g, h);
                         const float A = __expf(Sv[g] - smx) * sinv;
-                        dS[g] = j < N ? A * (dapark[(size_t)(t * 16 + g) * 64] - dot) + pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
+                        dS[g] = j < N ? A * (bf2f(dapark[(t * 16 + g) * 64]) - dot) + pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
                     }
                     bf16x8 lo, hi;
                     pack_tile_bf(lo, hi, dS);
-                    u32x4 *ps = slot(S_DS);
-                    ps[(2 * t) * 64] = as_u4(lo); ps[(2 * t + 1) * 64] = as_u4(hi);
+                    switch (t) {   // uniform: keeps the packed slab in VGPRs with a rolled tile loop
+#define MOPK_SP(K_) case K_: if (K_ < NT) { Sp[K_ < NT ? K_ : 0][0] = lo; Sp[K_ < NT ? K_ : 0][1] = hi; } break;
+                        MOPK_SP(0) MOPK_SP(1) MOPK_SP(2) MOPK_SP(3) MOPK_SP(4) MOPK_SP(5) MOPK_SP(6)
+#undef MOPK_SP
+                        default: break;
+                    }
                 }
             }
+            if (v == V - 1) STAMP();
+            REFRESH();
             // ---- dQe_v^T = K^T dS^T ; dq += sqk_v * dQe_v ; dsqk_v = sum_i q * dQe_v
-            bf16x8 Sp[NT][2];
-            slot_ld(S_DS, Sp);
             {
                 f32x16 dq[DT];
                 gemm_small(dq, KT, Sp);
@@ -1002,10 +1079,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     if ((r & 1) == 0 && d < DK) redbuf[w * DK + d] = c[0];
                 }
             }
+            if (v == V - 1) STAMP();
+            REFRESH();
             // ---- dK += sqk_v * (dS^T Q) through LDS
             __syncthreads();
-#pragma unroll
-            for (int t = 0; t < NT; ++t) store_i_tile(R, t, Sp[t][0], Sp[t][1]);
+            store_i_packed(R, Sp);
             __syncthreads();
             if (tid < DK) {
                 float s = 0.f;
@@ -1028,6 +1106,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     }
                 }
             }
+            if (v == V - 1) STAMP();
+            REFRESH();
             // ---- D_{v-1}^T = A_v D_v^T
             if (v >= 1) {
                 a_slab(X, v);
@@ -1040,6 +1120,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
         }
     }
+    STAMP();
+    REFRESH();
     // ================= P11: write dq, dk =================
     {
         IOT *dqp = (IOT *)a.dq.ptr + b * a.dq.sb + hh * a.dq.sh + (int64_t)qi * a.dq.sn;
@@ -1069,23 +1151,28 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
         }
     }
+    __syncthreads();      // LDS / scratch reuse by the next (b,h)
+    }   // persistent loop
+    STAMP();
 }
 
 // ------------------------------------------------------------------ host side (see edgewise_fused.hip)
 #define MOPK_CAT_(a, b, c, d) a##b##c##d
 #define MOPK_CAT(a, b, c, d) MOPK_CAT_(a, b, c, d)
 #if MOPK_INST_NT != 0
+static int bwd_grid(const MopkEdgewiseArgs *a) { const int bh = a->B * a->H; return bh < 256 ? bh : 256; }   // one persistent WG per CU
 size_t MOPK_CAT(ew_fused_bwd_ws_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a) {
-    return BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::carve(nullptr, a->V).stride * (size_t)a->B * a->H + 256;
+    return BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::carve(nullptr, a->V).stride * (size_t)bwd_grid(a) + 256;
 }
-void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, hipStream_t st);
+void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st);
 int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st) {
     constexpr int NT = MOPK_INST_NT, DK = MOPK_INST_DK;
     using Cfg = BwdCfg<NT, DK>;
     const int lds = Cfg::lds_bytes(a->V);
     if (lds > 160 * 1024 || 2 * a->V + 2 > 18) return MOPK_ERR_UNSUPPORTED;
     const BwdWs W = Cfg::carve(a->workspace, a->V);
-    const dim3 grid(a->B * a->H), block(NT * 64);
+    const int nwg = bwd_grid(a);
+    const dim3 grid(nwg), block(NT * 64);
     if (a->io_dtype == MOPK_BF16) {
         auto kfn = ew_fused_bwd_kernel<NT, DK, unsigned short>;
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
@@ -1096,7 +1183,7 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
         hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);
     }
     MOPK_CHECK_LAUNCH();
-    ew_fused_dw_reduce(a, W, st);
+    ew_fused_dw_reduce(a, W, nwg, st);
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
 }
@@ -1118,9 +1205,9 @@ __global__ void ew_fused_dw_reduce_kernel(MopkEdgewiseArgs a, BwdWs W, int nwg) 
     if (c < C) (side ? a.dWc : a.dWr)[o * C + c] = s; else (side ? a.dbc : a.dbr)[o] = s;
 }
 
-void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, hipStream_t st) {
+void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st) {
     const int nout = 2 * 4 * a->r * (2 * a->V + 3);
-    hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3(nout), dim3(256), 0, st, *a, W, a->B * a->H);
+    hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3(nout), dim3(256), 0, st, *a, W, nwg);
 }
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 #define MOPK_DECL(NT_, DK_) int ew_fused_bwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st); \

@@ -203,6 +203,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.dlogit_part = dlg.data_ptr()
         LAST_PATH["edgewise_bwd"] = path
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
+        LAST_PATH["_bwd_ws"] = ws  # kept for diagnostics (stamp builds read it back)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("edgewise_bwd"):
             rc = lib.mopk_edgewise_lowrank_bwd(C.byref(a), _stream())
