@@ -39,11 +39,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     float *rS = colpart + NT * NP, *cS = rS + a.V * NP;            // [V][NP]
     float *wsig = cS + a.V * NP;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int tid = threadIdx.x, w = tid >> 6;
+    int lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int N = a.N, V = a.V, H = a.H, R = a.r;
     const int b = blockIdx.x / H, hh = blockIdx.x % H;
-    const int qi = 32 * w + r;                 // this lane's query
-    const bool qok = qi < N;
+    int qi = 32 * w + r;                       // this lane's query
+    bool qok = qi < N;
+    // REFRESH(): opaque lane id per phase so lane-derived addresses are recomputed instead of hoisted + spilled
+#define REFRESH() do { asm volatile("" : "+v"(lane)); r = lane & 31; h = lane >> 5; qi = 32 * w + r; qok = qi < N; } while (0)
     const float invN = 1.f / (float)N;
 
     // ---------------- P0: stage K, q fragments, scales ----------------
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bf16x8 af = *(const bf16x8 *)&Ksm[(32 * t + r) * LDK + 16 * s + 8 * h];
+            const bf16x8 af = *(const bf16x8 *)&(Ksm + r * LDK + 8 * h)[(32 * t) * LDK + 16 * s];
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qe[s], acc, 0, 0, 0);
         }
         return acc;
@@ -157,11 +160,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         for (int t = 0; t < NT; ++t) X[t] *= inv;
     };
     auto store_AT = [&](const f32x16 (&X)[NT]) {   // AT[j][perm(i)] = X^T slab
-        const int col = 32 * w + 16 * (r >> 4) + kperm16(r & 15);
+        unsigned short *base = AT + (4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) AT[(32 * t + tile_row(g, h)) * LDA + col] = f2bf(X[t][g]);
+            for (int g = 0; g < 16; ++g) base[(32 * t + (g & 3) + 8 * (g >> 2)) * LDA] = f2bf(X[t][g]);
     };
     auto chain_gemm = [&](f32x16 (&Xn)[NT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
 #pragma unroll
@@ -171,7 +174,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 af = *(const bf16x8 *)&Am[(32 * to + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
                 }
             Xn[to] = acc;
@@ -224,11 +227,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     };
 
     f32x16 X[NT];
+    REFRESH();
     // ---------------- chain <- : only its log-means survive           :513-515, :521
     run_chain(X, false);
     log_means(X, rCl);
     __syncthreads();
     if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
+    REFRESH();
     // ---------------- chain -> : C->^T stays in X                      :508-512, :520
     run_chain(X, true);
     __syncthreads();                      // AT free: build V0^T, VL^T (k-permuted key columns)
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 af = *(const bf16x8 *)&VTL[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                    const bf16x8 af = *(const bf16x8 *)&(VTL + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
                 }
             if (qok) {
@@ -284,6 +289,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(X[t][2 * p], X[t][2 * p + 1]);
     __syncthreads();                      // cCr visible
+    REFRESH();
     // ---------------- gate vectors                                     :323-326
     const int C = 2 * V + 2;
     if (tid < NP) {                       // b[g,k,j] -> bT[g][j][slots] = [b_hi | b_hi | b_lo | 0]
@@ -325,6 +331,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
     }
     __syncthreads();                      // bT complete
+    REFRESH();
     // ---------------- score-space mix, tile by tile                    :537-547
     const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
     float mxrow = -INFINITY;
@@ -406,6 +413,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             default: break;
         }
     }
+    REFRESH();
     // ---------------- softmax over keys + P V0                         :551-554
     mxrow = fmaxf(mxrow, __shfl_xor(mxrow, 32, 64));
     float l = 0.f;
@@ -428,7 +436,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 af = *(const bf16x8 *)&VT0[(32 * dt + r) * LDA + 32 * t + 16 * s + 8 * h];
+                const bf16x8 af = *(const bf16x8 *)&(VT0 + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Pp[t][s], acc, 0, 0, 0);
             }
         if (qok) {

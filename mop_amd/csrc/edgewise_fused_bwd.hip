@@ -45,7 +45,7 @@ struct BwdCfg {
         w.oSlots = o; o += a256((size_t)(S_DL + V) * NT * SLOT);
         w.oStats = o; o += a256((size_t)V * NP * 2 * 4);
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
-        w.oAcc = o; o += a256((size_t)2 * NT * DT * 16 * 64 * 4);
+        w.oAcc = o; o += a256((size_t)2 * V * NT * DT * 16 * 64 * 4);   // per-view dq / dk partials (write-only, summed in P11)
         w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
         w.oDA = o; o += a256((size_t)NT * NT * 16 * 64 * 4);     // fp32 dA slab of every wave
         w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds)
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     unsigned short *V0s = (unsigned short *)(ws + W.oV0s), *VLs = (unsigned short *)(ws + W.oVLs);
     float *stats = (float *)(ws + W.oStats);                          // [V][NP][2]  (row max, 1/row sum)
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
-    float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)NT * DT * 16 * 64;
+    float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)a.V * NT * DT * 16 * 64;   // [V][NT][DT*16][64]
     float *dwp = (float *)(ws + W.oDW);
     auto slot = [&](int s) -> u32x4 * { return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane; };
     // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
@@ -349,6 +349,29 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
             }
     };
+    auto load_rows = [&](bf16x8 (&Bf)[NT][2], const unsigned short *Bm) {      // this lane's row of a global AT image (14 x 16 B)
+        const unsigned short *brow = Bm + (size_t)qi * LDA + 8 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) Bf[t][s] = *(const bf16x8 *)&brow[32 * t + 16 * s];
+    };
+    auto gemm_lds_pre = [&](f32x16 (&acc)[NT], const unsigned short *Am, const bf16x8 (&Bf)[NT][2]) {   // acc[to] += Am rows . Bf
+#pragma unroll
+        for (int to = 0; to < NT; ++to) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
+                    acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Bf[t][s], acc[to], 0, 0, 0);
+                }
+        }
+    };
+    // barrier for LDS-only hand-offs: global loads / stores stay in flight across it (a __syncthreads() fence
+    // would drain vmcnt and expose every prefetch)
+    auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     // out[dt] = Am[d][:] . Xp   (A rows d from a [DP][LDA] image, contraction over the slab's rows)
     auto gemm_small = [&](f32x16 (&out)[DT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
 #pragma unroll
@@ -904,9 +927,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             pack_all(Dp, X);
             slot_st(S_DL + m, Dp);
             a_slab(X, V - 1 - m);                      // A_av slab (rows = my queries)
-            __syncthreads();
+            lds_barrier();
             store_ii(R, X);
-            __syncthreads();
+            lds_barrier();
             gemm_lds_reg(X, R, Dp);                    // D'_{m-1}^T = A_av D'_m^T
         }
         bf16x8 Dp[NT][2];
@@ -942,12 +965,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             REFRESH();
             // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index)
             if (v >= 1) {
-                __syncthreads();
+                bf16x8 Bf[NT][2];
+                load_rows(Bf, Tg + (size_t)(v - 1) * NP * LDA);          // in flight across the barriers below
+                lds_barrier();
                 store_i_packed(R, Dp);
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) X[t] = zero16();
-                gemm_lds_glob(X, R, Tg + (size_t)(v - 1) * NP * LDA);
+                gemm_lds_pre(X, R, Bf);
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) X[t] = unpack_tile_bf(Dp[t][0], Dp[t][1]);
@@ -957,10 +982,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 bf16x8 Dl[NT][2];
                 slot_ld(S_DL + mp, Dl);
                 if (mp >= 1) {
-                    __syncthreads();
+                    bf16x8 Bf[NT][2];
+                    load_rows(Bf, Ug + (size_t)(mp - 1) * NP * LDA);
+                    lds_barrier();
                     store_i_packed(R, Dl);
-                    __syncthreads();
-                    gemm_lds_glob(X, R, Ug + (size_t)(mp - 1) * NP * LDA);
+                    lds_barrier();
+                    gemm_lds_pre(X, R, Bf);
                 } else {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) X[t] += unpack_tile_bf(Dl[t][0], Dl[t][1]);
@@ -972,7 +999,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             //      private 14 KB of the R region, which is idle between the dA GEMMs and the dS^T image: the tile
             //      loops below stay rolled with the whole register file free (keeping dA in VGPRs made hipcc
             //      spill ~8000 registers around the rolled loops).
-            __syncthreads();                               // every wave is done reading the D images in R
+            lds_barrier();                                 // every wave is done reading the D images in R
             unsigned short *dapark = R + (size_t)w * NT * 16 * 64 + lane;    // [(t*16+g)][lane]
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -992,6 +1019,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
                 dot += __shfl_xor(dot, 32, 64);
                 const float drs = dmean[v * NP + qi];
+                bf16x8 qe0[KS];
+                if (v != 0) make_frag(qe0, qrow, sqk);
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x16 Sv = s_tile(qe, t);
@@ -1000,8 +1029,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         const u32x4 *p = slot(S_L);
                         pi = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);        // L = lse - S0
                         if (v != 0) {
-                            bf16x8 qe0[KS];
-                            make_frag(qe0, qrow, sqk);
                             const f32x16 S0 = s_tile(qe0, t);
 #pragma unroll
                             for (int g = 0; g < 16; ++g) pi[g] = __expf(Sv[g] - S0[g] - pi[g]);
@@ -1041,7 +1068,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             {
                 f32x16 dq[DT];
                 gemm_small(dq, KT, Sp);
-                float *acc = dqacc + ((size_t)w * DT * 16) * 64 + lane;
+                float *acc = dqacc + (((size_t)v * NT + w) * DT * 16) * 64 + lane;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     float c[16];
@@ -1057,9 +1084,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         for (int e = 0; e < 4; ++e) {
                             const int g = 4 * g4 + e;
                             const float sc = d0 < DK ? sqk[v * DK + d0 + e] : 0.f;
-                            float *p = acc + (size_t)(dt * 16 + g) * 64;
-                            const float prev = v == V - 1 ? 0.f : *p;
-                            *p = fmaf(sc, dq[dt][g], prev);
+                            acc[(size_t)(dt * 16 + g) * 64] = sc * dq[dt][g];
                             c[g] = qok ? qv[e] * dq[dt][g] : 0.f;
                         }
                     }
@@ -1082,9 +1107,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             if (v == V - 1) STAMP();
             REFRESH();
             // ---- dK += sqk_v * (dS^T Q) through LDS
-            __syncthreads();
+            lds_barrier();
             store_i_packed(R, Sp);
-            __syncthreads();
+            lds_barrier();
             if (tid < DK) {
                 float s = 0.f;
                 for (int ww = 0; ww < NT; ++ww) s += redbuf[ww * DK + tid];
@@ -1093,28 +1118,24 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             {
                 f32x16 dk[DT];
                 gemm_rows_glob(dk, R, QT);             // (dS^T q)[j in tile w][d]
-                float *acc = dkacc + ((size_t)w * DT * 16) * 64 + lane;
+                float *acc = dkacc + (((size_t)v * NT + w) * DT * 16) * 64 + lane;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const int d = 32 * dt + r;
                     const float sc = d < DK ? sqk[v * DK + d] : 0.f;
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        float *p = acc + (size_t)(dt * 16 + g) * 64;
-                        const float prev = v == V - 1 ? 0.f : *p;
-                        *p = fmaf(sc, dk[dt][g], prev);
-                    }
+                    for (int g = 0; g < 16; ++g) acc[(size_t)(dt * 16 + g) * 64] = sc * dk[dt][g];
                 }
             }
             if (v == V - 1) STAMP();
             REFRESH();
             // ---- D_{v-1}^T = A_v D_v^T
             if (v >= 1) {
+                slot_ld(S_DP, Dp);                 // issued early: consumed after the A_v image is staged
                 a_slab(X, v);
-                __syncthreads();
+                lds_barrier();
                 store_ii(R, X);
-                __syncthreads();
-                slot_ld(S_DP, Dp);
+                lds_barrier();
                 gemm_lds_reg(X, R, Dp);
                 pack_all(Dp, X);
             }
@@ -1122,19 +1143,24 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     }
     STAMP();
     REFRESH();
-    // ================= P11: write dq, dk =================
+    // ================= P11: write dq, dk (sum of the per-view partials) =================
     {
         IOT *dqp = (IOT *)a.dq.ptr + b * a.dq.sb + hh * a.dq.sh + (int64_t)qi * a.dq.sn;
         const float *acc = dqacc + ((size_t)w * DT * 16) * 64 + lane;
+        const size_t vs = (size_t)NT * DT * 16 * 64;
         if (qok) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int d0 = 32 * dt + 8 * g4 + 4 * h;
-                    if (d0 < DK)
-                        store4<IOT>(dqp + d0, acc[(size_t)(dt * 16 + 4 * g4) * 64], acc[(size_t)(dt * 16 + 4 * g4 + 1) * 64],
-                                    acc[(size_t)(dt * 16 + 4 * g4 + 2) * 64], acc[(size_t)(dt * 16 + 4 * g4 + 3) * 64]);
+                    if (d0 < DK) {
+                        float o[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int v = 0; v < V; ++v)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += acc[v * vs + (size_t)(dt * 16 + 4 * g4 + e) * 64];
+                        store4<IOT>(dqp + d0, o[0], o[1], o[2], o[3]);
+                    }
                 }
         }
         IOT *dkp = (IOT *)a.dk_.ptr + b * a.dk_.sb + hh * a.dk_.sh;
@@ -1146,7 +1172,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * w + tile_row(g, h);
-                    if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, kacc[(size_t)(dt * 16 + g) * 64]);
+                    float o = 0.f;
+                    for (int v = 0; v < V; ++v) o += kacc[v * vs + (size_t)(dt * 16 + g) * 64];
+                    if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, o);
                 }
             }
         }

@@ -18,7 +18,7 @@ from mop_amd import _lib as L
 a = L.EdgewiseArgs(); a.B, a.H, a.N, a.dk, a.V, a.r = B, 6, 197, 64, 5, 4; a.path = L.PATH_FUSED; a.precision = L.PREC_BF16
 a.io_dtype = L.MOPK_BF16
 tot = L.lib().mopk_edgewise_workspace_bytes(C.byref(a))
-stride = (tot - 256) // (B * 6)
+stride = (tot - 256) // min(B * 6, 256)
 raw = ws[stride - 512: stride].cpu().numpy().tobytes()
 st = struct.unpack("64Q", raw)
 names = ["P0 stage", "P1/2 fwd chains", "P3 gates", "P4 mix", "P5 delta", "P6 mix bwd", "P7 gate grads", "P8 dv", "P9 <-D chain",
