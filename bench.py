@@ -111,7 +111,8 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     x = torch.randn(B, NS["N"], NS["D"], device="cuda", dtype=dtype, generator=g).requires_grad_(True)
     dy = torch.randn(B, NS["N"], NS["D"], device="cuda", dtype=dtype, generator=g)
-    flat = torch.zeros(sum(p.numel() for p in params), device="cuda", dtype=torch.float32)
+    from mop_amd.parallel import FlatGradBucket
+    bucket = FlatGradBucket(params)
 
     def step():
         for p in params:
@@ -120,9 +121,7 @@ def main():
         y = layer(x)
         y.backward(dy)
         if world > 1:  # one flat gradient bucket, one RCCL all-reduce over xGMI
-            torch.cat([p.grad.reshape(-1).float() for p in params], out=flat)
-            dist.all_reduce(flat)
-            flat.div_(world)
+            bucket.allreduce_(average=True)
 
     for _ in range(args.warmup):
         step()
@@ -150,7 +149,13 @@ def main():
         a = L.EdgewiseArgs()
         a.B, a.H, a.N, a.dk, a.V, a.r = B, NS["H"], NS["N"], NS["D"] // NS["H"], NS["V"], NS["r"]
         a.precision = L.PREC_BF16 if args.dtype == "bf16" else L.PREC_FP32
+        a.io_dtype = L.MOPK_BF16 if args.dtype == "bf16" else L.MOPK_F32
+        a.path = ops.LAST_PATH.get("edgewise_bwd", L.PATH_AUTO)
         dom_bwd = L.lib().mopk_edgewise_dominant_kernel(C.byref(a), 1).decode()
+        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/*hbm_traffic.json), if collected
+        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tpath) and B == NS["B"]:
+            traffic = json.load(open(tpath)).get(dom_bwd, {}).get("hbm_bytes_per_launch")
         fwd_ms = sum(tim.get("edgewise_fwd", [0.0])) / max(1, len(tim.get("edgewise_fwd", [])))
         bwd_ms = sum(tim.get("edgewise_bwd", [0.0])) / max(1, len(tim.get("edgewise_bwd", [])))
         # dominant launch = the backward core (2/3 of the algorithmic FLOPs)
@@ -168,7 +173,7 @@ def main():
                        "share_qkv": True, "gate_mode": "lowrank",
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": {"bound": "mfma", "kernel": dom_bwd, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "launch_ms": bwd_ms, "algorithmic_flop_per_launch": B * CORE_FLOP_BWD,
                          "fwd": {"launch_ms": fwd_ms, "achieved": ach_fwd, "frac": ach_fwd / PEAK_BF16_TFLOPS},
                          "core_fwd_bwd_frac": (B * (CORE_FLOP_FWD + CORE_FLOP_BWD) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12

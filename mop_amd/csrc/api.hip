@@ -57,8 +57,9 @@ const char *mopk_strerror(int s) {
 int mopk_edgewise_fused_supported(const MopkEdgewiseArgs *a) { return a ? ew_fused_fwd_supported(a) : 0; }
 
 const char *mopk_edgewise_dominant_kernel(const MopkEdgewiseArgs *a, int backward) {
-    (void)a; (void)backward;
-    return "bgemm_kernel";
+    const bool fused = a && a->path != MOPK_PATH_GENERIC && ew_fused_fwd_supported(a);
+    if (!fused) return "bgemm_kernel";
+    return backward ? "ew_fused_bwd_kernel" : "ew_fused_fwd_kernel";
 }
 
 size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a) {

@@ -133,146 +133,185 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
         return acc;
     };
-    // A_v^T slab = softmax over keys (registers) of S_v^T            :500-507
-    auto a_slab = [&](f32x16 (&X)[NT], int v) {
-        bf16x8 qe[KS];
-        make_qe(qe, v);
-        float mx = -INFINITY;
-#pragma unroll
+    // ---- tile-streamed primitives: no N x 32 fp32 slab is ever held in registers; chain state lives as packed
+    //      bf16 B-operand fragments (8 VGPRs per 32x32 tile), accumulators are consumed tile by tile.
+    constexpr float NEG = -1e30f;                     // finite "-inf" (keeps the online softmax NaN-free)
+    // row statistics of softmax_j S_v[i, j] for this lane's query, online over key tiles   :500-507
+    auto row_stats = [&](const bf16x8 (&qe)[KS], float &mx, float &inv) {
+        float m = NEG, l = 0.f;
+#pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
-            X[t] = s_tile(qe, t);
+            f32x16 S = s_tile(qe, t);
+            float tm = NEG;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                if (32 * t + tile_row(g, h) >= N) X[t][g] = -INFINITY;
-                mx = fmaxf(mx, X[t][g]);
+            for (int g = 0; g < 16; ++g) { if (32 * t + tile_row(g, h) >= N) S[g] = NEG; tm = fmaxf(tm, S[g]); }
+            const float mn = fmaxf(m, tm);
+            float sm = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sm += __expf(S[g] - mn);
+            l = fmaf(l, __expf(m - mn), sm);
+            m = mn;
+        }
+        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+        mx = fmaxf(m, m2);
+        inv = 1.f / (l * __expf(m - mx) + l2 * __expf(m2 - mx));
+    };
+    auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float mx, float inv) -> f32x16 {   // A_v^T tile (masked rows -> 0)
+        f32x16 S = s_tile(qe, t);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) S[g] = (32 * t + tile_row(g, h) < N) ? __expf(S[g] - mx) * inv : 0.f;
+        return S;
+    };
+    auto pack_tile = [&](bf16x8 &lo, bf16x8 &hi, const f32x16 &x) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { lo[j] = (short)f2bf(x[j]); hi[j] = (short)f2bf(x[8 + j]); }
+    };
+    auto store_AT_tile = [&](int t, bf16x8 lo, bf16x8 hi) {      // AT[key][perm(query)] for one tile
+        unsigned short *base = AT + (32 * t + 4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            base[((g & 3) + 8 * (g >> 2)) * LDA] = (unsigned short)lo[g];
+            base[((g & 3) + 8 * (g >> 2) + 16) * LDA] = (unsigned short)hi[g];
+        }
+    };
+    auto gemm_tile = [&](int to, const bf16x8 (&Xp)[NT][2]) -> f32x16 {        // (A_m^T . X)[tile to]
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 af = *(const bf16x8 *)&(AT + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
+            }
+        return acc;
+    };
+    // epilogue of the LAST chain step for one output tile: v = log(C + eps); row-sum, per-wave column partials
+    // (butterfly over the 32 lanes of a half: 16 shuffles per tile; lane r even ends with register r>>1)
+    auto log_tile = [&](f32x16 &X, int t, float &rs) {
+        float c[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float v = __logf(X[g] + EPSC);
+            X[g] = v;
+            rs += (32 * t + tile_row(g, h) < N) ? v : 0.f;
+            c[g] = qok ? v : 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int n = 8 >> st;
+            const bool up = (r >> (4 - st)) & 1;
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                const float keep = up ? c[k + n] : c[k], send = up ? c[k] : c[k + n];
+                c[k] = keep + __shfl_xor(send, 16 >> st, 64);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sm = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) { const float e = __expf(X[t][g] - mx); X[t][g] = e; sm += e; }
-        sm += __shfl_xor(sm, 32, 64);
-        const float inv = 1.f / sm;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) X[t] *= inv;
+        c[0] += __shfl_xor(c[0], 1, 64);
+        if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
     };
-    auto store_AT = [&](const f32x16 (&X)[NT]) {   // AT[j][perm(i)] = X^T slab
-        unsigned short *base = AT + (4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int g = 0; g < 16; ++g) base[(32 * t + (g & 3) + 8 * (g >> 2)) * LDA] = f2bf(X[t][g]);
-    };
-    auto chain_gemm = [&](f32x16 (&Xn)[NT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
-#pragma unroll
-        for (int to = 0; to < NT; ++to) {
-            f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
-                }
-            Xn[to] = acc;
-        }
-    };
-    // chain product over views order[0..V-1] (transposed): X <- A_{o[V-1]}^T .. A_{o[1]}^T A_{o[0]}^T[:, I]
-    auto run_chain = [&](f32x16 (&X)[NT], bool forward) {
+    // chain product (transposed, row-block local):  X <- A_{o[V-1]}^T .. A_{o[1]}^T A_{o[0]}^T[:, I]
+    // the last step hands every fp32 output tile to `epi(to, acc)`
+    auto run_chain = [&](bool forward, auto &&epi) {
         bf16x8 Xp[NT][2];
-        a_slab(X, forward ? 0 : V - 1);
+        {
+            bf16x8 qe[KS];
+            float mx, inv;
+            make_qe(qe, forward ? 0 : V - 1);
+            row_stats(qe, mx, inv);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, mx, inv); pack_tile(Xp[t][0], Xp[t][1], A); }
+        }
         for (int m = 1; m < V; ++m) {
-            pack_slab<NT>(Xp, X);
-            a_slab(X, forward ? m : V - 1 - m);
-            __syncthreads();              // previous step's readers of AT are done
-            store_AT(X);
-            __syncthreads();
-            chain_gemm(X, AT, Xp);
-        }
-    };
-    // X <- log(X + eps) ; row means -> rout[i] ; per-wave column partial sums -> colpart[w][j]
-    // column sums over the 32 lanes of a half: butterfly that halves the live registers each
-    // step (16 shuffles per tile instead of 80); lane r (even) ends with the sum of register r>>1.
-    auto log_means = [&](f32x16 (&X)[NT], float *rout) {
-        float rs = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            float c[16];
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float v = __logf(X[t][g] + EPSC);
-                X[t][g] = v;
-                rs += (32 * t + tile_row(g, h) < N) ? v : 0.f;
-                c[g] = qok ? v : 0.f;
-            }
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {          // xor 16, 8, 4, 2
-                const int n = 8 >> st;                 // registers kept after this step
-                const bool up = (r >> (4 - st)) & 1;
-#pragma unroll
-                for (int k = 0; k < n; ++k) {
-                    const float keep = up ? c[k + n] : c[k];
-                    const float send = up ? c[k] : c[k + n];
-                    c[k] = keep + __shfl_xor(send, 16 >> st, 64);
+            {
+                bf16x8 qe[KS];
+                float mx, inv;
+                make_qe(qe, forward ? m : V - 1 - m);
+                row_stats(qe, mx, inv);
+                __syncthreads();              // previous step's readers of AT are done
+#pragma nounroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x16 A = a_tile(qe, t, mx, inv);
+                    bf16x8 lo, hi;
+                    pack_tile(lo, hi, A);
+                    store_AT_tile(t, lo, hi);
                 }
+                __syncthreads();
             }
-            c[0] += __shfl_xor(c[0], 1, 64);
-            if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
+            if (m < V - 1) {
+                bf16x8 Xn[NT][2];
+#pragma unroll
+                for (int to = 0; to < NT; ++to) { const f32x16 acc = gemm_tile(to, Xp); pack_tile(Xn[to][0], Xn[to][1], acc); }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
+            } else {
+#pragma unroll
+                for (int to = 0; to < NT; ++to) { f32x16 acc = gemm_tile(to, Xp); epi(to, acc); }
+            }
         }
-        rs += __shfl_xor(rs, 32, 64);
-        if (h == 0) rout[qi] = rs * invN;
     };
 
-    f32x16 X[NT];
     REFRESH();
     // ---------------- chain <- : only its log-means survive           :513-515, :521
-    run_chain(X, false);
-    log_means(X, rCl);
+    {
+        float rs = 0.f;
+        run_chain(false, [&](int to, f32x16 &acc) { log_tile(acc, to, rs); });
+        rs += __shfl_xor(rs, 32, 64);
+        if (h == 0) rCl[qi] = rs * invN;
+    }
     __syncthreads();
     if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
     REFRESH();
-    // ---------------- chain -> : C->^T stays in X                      :508-512, :520
-    run_chain(X, true);
-    __syncthreads();                      // AT free: build V0^T, VL^T (k-permuted key columns)
-    {
-        const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
-        const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
-        constexpr int CH = DK / 8;
-        for (int c = tid; c < NP * CH; c += NT * 64) {
-            const int j = c / CH, dc = c % CH;
-            bf16x8 x0 = {0, 0, 0, 0, 0, 0, 0, 0}, xL = x0;
-            if (j < N) { x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8); xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8); }
-            const int col = (j & ~15) + kperm16(j & 15);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = dc * 8 + e;
-                VT0[d * LDA + col] = f2bf(bf2f((unsigned short)x0[e]) * vs0[d]);
-                VTL[d * LDA + col] = f2bf(bf2f((unsigned short)xL[e]) * vsL[d]);
-            }
-        }
-        if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NT * 64) { VT0[DK * LDA + c] = 0; VTL[DK * LDA + c] = 0; }
-    }
+    // ---------------- chain -> : C-> kept as packed bf16 (for y_chain) and log C-> as packed fp16 (for the mix)
+    unsigned int crp[NT][8];              // Cr (later Smix) as packed fp16
     IOT *yp = (IOT *)a.y.ptr + b * a.y.sb + hh * a.y.sh + (int64_t)qi * a.y.sn;
     float *ych = (float *)a.saved + (size_t)blockIdx.x * N * DK;   // saved: w * y_chain (BH,N,dk) fp32
     {
-        bf16x8 Xp[NT][2];
-        pack_slab<NT>(Xp, X);
-        log_means(X, rCr);                // X = Cr
-        __syncthreads();                  // VT*, colpart complete
-        if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
+        bf16x8 Xc[NT][2];
+        run_chain(true, [&](int to, f32x16 &acc) { pack_tile(Xc[to][0], Xc[to][1], acc); });
+        // log C-> from the bf16-rounded product (the same rounding the backward sees): means + packed fp16 copy
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { c[j] = bf2f((unsigned short)Xc[t][0][j]); c[8 + j] = bf2f((unsigned short)Xc[t][1][j]); }
+            log_tile(c, t, rs);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(c[2 * p], c[2 * p + 1]);
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        if (h == 0) rCr[qi] = rs * invN;
+        __syncthreads();                      // AT free: build V0^T, VL^T (k-permuted key columns); colpart complete
+        {
+            const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
+            const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
+            constexpr int CH = DK / 8;
+            for (int c = tid; c < NP * CH; c += NT * 64) {
+                const int j = c / CH, dc = c % CH;
+                bf16x8 x0 = {0, 0, 0, 0, 0, 0, 0, 0}, xL = x0;
+                if (j < N) { x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8); xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8); }
+                const int col = (j & ~15) + kperm16(j & 15);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int d = dc * 8 + e;
+                    VT0[d * LDA + col] = f2bf(bf2f((unsigned short)x0[e]) * vs0[d]);
+                    VTL[d * LDA + col] = f2bf(bf2f((unsigned short)xL[e]) * vsL[d]);
+                }
+            }
+            if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NT * 64) { VT0[DK * LDA + c] = 0; VTL[DK * LDA + c] = 0; }
+            if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
+        }
+        __syncthreads();                      // VT*, cCr complete
         const float wv = wsig[0];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {  // y_chain^T = VL^T C->^T       :556-560 (as C-> vL); parked in y
+        for (int dt = 0; dt < DT; ++dt) {     // y_chain^T = VL^T C->^T       :556-560 (as C-> vL); parked in `saved`
             f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 af = *(const bf16x8 *)&(VTL + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xc[t][s], acc, 0, 0, 0);
                 }
             if (qok) {
 #pragma unroll
@@ -283,12 +322,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             }
         }
     }
-    unsigned int crp[NT][8];              // Cr (later Smix) as packed fp16
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(X[t][2 * p], X[t][2 * p + 1]);
-    __syncthreads();                      // cCr visible
     REFRESH();
     // ---------------- gate vectors                                     :323-326
     const int C = 2 * V + 2;

@@ -1,0 +1,59 @@
+"""Data-parallel helper: ONE flat gradient bucket, ONE all-reduce per step.
+
+The attention path shards over batch with no data-path collective; the only exchange is the
+DDP-equivalent gradient sum of the reference's single-process loop
+(experiments/cifar100_ab5_param_budgets.py:799-804).  Backend "nccl" is RCCL over xGMI on ROCm;
+the same code runs on "gloo" for the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradBucket:
+    """Packs the gradients of `params` into one contiguous fp32 buffer, all-reduces it once and
+    scatters the averaged values back.  21.6 MB for the 5.4 M-parameter ViT-MoP: a single ring
+    all-reduce moves 2*(n-1)/n of it per GPU, far below one xGMI link-millisecond."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.group = group
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.offsets = []
+        o = 0
+        for p in self.params:
+            self.offsets.append((o, o + p.numel()))
+            o += p.numel()
+
+    def allreduce_(self, average: bool = True) -> None:
+        """sum (then average) gradients across ranks, in place on each p.grad."""
+        if not dist.is_available() or not dist.is_initialized():
+            return
+        world = dist.get_world_size(self.group)
+        if world == 1:
+            return
+        for p, (s, e) in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None:
+                self.flat[s:e].zero_()
+            else:
+                self.flat[s:e].copy_(g.reshape(-1))
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if average:
+            self.flat.div_(world)
+        for p, (s, e) in zip(self.params, self.offsets):
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self.flat[s:e].view_as(p))
+
+
+def shard_batch(n_items: int, rank: int, world: int):
+    """contiguous, balanced [start, end) shard of a batch dimension (strong-scaling helper)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)

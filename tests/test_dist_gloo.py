@@ -1,0 +1,67 @@
+"""world_size-2 gloo test of the data-parallel gradient exchange (the only collective on the path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mop_amd.parallel import FlatGradBucket, shard_batch
+    torch.manual_seed(0)  # same init on every rank
+    from mop_amd.nn import EdgewiseMSA
+    m = EdgewiseMSA(32, 2, n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2)
+    # synthetic per-rank gradients: rank-dependent but known
+    for i, p in enumerate(m.parameters()):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    list(m.parameters())[3].grad = None  # a parameter that received no gradient on this rank
+    b = FlatGradBucket(m.parameters())
+    b.allreduce_(average=True)
+    ok = True
+    for i, p in enumerate(m.parameters()):
+        exp = sum((r + 1) * (i + 1) for r in range(world)) / world if i != 3 else 0.0
+        ok &= bool(torch.allclose(p.grad, torch.full_like(p, exp)))
+    s, e = shard_batch(10, rank, world)
+    q.put((rank, ok, (s, e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert [r[2] for r in res] == [(0, 5), (5, 10)]
+
+
+def test_shard_batch_covers_everything():
+    from mop_amd.parallel import shard_batch
+    for n in (1, 7, 256, 2048):
+        for world in (1, 2, 3, 8):
+            spans = [shard_batch(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
