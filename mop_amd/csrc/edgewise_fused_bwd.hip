@@ -252,30 +252,26 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
         return acc;
     };
-    auto a_slab = [&](f32x16 (&X)[NT], int v) {     // softmax_j(S_v^T) slab + row stats
-        bf16x8 qe[KS];
-        make_frag(qe, qrow, sqk + v * DK);
-        float mx = -INFINITY;
-#pragma unroll
+    constexpr float NEG = -1e30f;                     // finite "-inf" (keeps the online softmax NaN-free)
+    // row statistics of softmax_j S_v[i, :] for this lane's query, online over key tiles; parked in `stats`
+    auto row_stats = [&](const bf16x8 (&qe)[KS], int v, float &mx, float &inv) {
+        float m = NEG, l = 0.f;
+#pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
-            X[t] = s_tile(qe, t);
+            f32x16 S = s_tile(qe, t);
+            float tm = NEG;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { if (32 * t + tile_row(g, h) >= N) X[t][g] = -INFINITY; mx = fmaxf(mx, X[t][g]); }
+            for (int g = 0; g < 16; ++g) { if (32 * t + tile_row(g, h) >= N) S[g] = NEG; tm = fmaxf(tm, S[g]); }
+            const float mn = fmaxf(m, tm);
+            float sm = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sm += __expf(S[g] - mn);
+            l = fmaf(l, __expf(m - mn), sm);
+            m = mn;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sm = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) { const float e = __expf(X[t][g] - mx); X[t][g] = e; sm += e; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        sm += __shfl_xor(sm, 32, 64);
-        const float inv = 1.f / sm;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) X[t] *= inv;
+        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
+        mx = fmaxf(m, m2);
+        inv = 1.f / (l * __expf(m - mx) + l2 * __expf(m2 - mx));
         if (h == 0) { stats[(v * NP + qi) * 2] = mx; stats[(v * NP + qi) * 2 + 1] = inv; }
     };
     auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float mx, float inv) -> f32x16 {   // one tile of A_v^T from saved stats
@@ -284,17 +280,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int g = 0; g < 16; ++g) s[g] = (32 * t + tile_row(g, h) < N) ? __expf(s[g] - mx) * inv : 0.f;
         return s;
     };
-    // form (i): dst[j][perm(i)] = X^T slab (A operand for products contracting over QUERIES)
-    auto store_i = [&](unsigned short *dst, const f32x16 (&X)[NT]) {
-        unsigned short *base = dst + (4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 16; ++g) base[(32 * t + (g & 3) + 8 * (g >> 2)) * LDA] = f2bf(X[t][g]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
+    // form (i): dst[j][perm(i)] = X^T tile (A operand for products contracting over QUERIES)
     auto store_i_tile = [&](unsigned short *dst, int t, bf16x8 lo, bf16x8 hi) {
         unsigned short *base = dst + (32 * t + 4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
 #pragma unroll
@@ -303,51 +289,49 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             base[((g & 3) + 8 * (g >> 2) + 16) * LDA] = (unsigned short)hi[g];
         }
     };
-    // form (ii): dst[i][perm(j)] = slab rows (A operand for products contracting over KEYS)
-    auto store_ii = [&](unsigned short *dst, const f32x16 (&X)[NT]) {
+    // form (ii): dst[i][perm(j)] = tile rows (A operand for products contracting over KEYS)
+    auto store_ii_tile = [&](unsigned short *dst, int t, const f32x16 &X) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                // regs 4g4..4g4+3 <-> keys 32t + 8g4 + 4h + {0..3}; permuted position keeps the low 2 bits
-                // permuted position of key 32t + 8g4 + 4h: 16-group base + (8h + 4(g4&1))
-                *(uint2 *)&(dst + qi * LDA + 8 * h)[32 * t + 16 * (g4 >> 1) + 4 * (g4 & 1)] = make_uint2(pack_bf16(X[t][4 * g4], X[t][4 * g4 + 1]), pack_bf16(X[t][4 * g4 + 2], X[t][4 * g4 + 3]));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int g4 = 0; g4 < 4; ++g4)   // regs 4g4..4g4+3 <-> keys 32t + 8g4 + 4h + {0..3}; permuted position: 16-group base + 8h + 4(g4&1)
+            *(uint2 *)&(dst + qi * LDA + 8 * h)[32 * t + 16 * (g4 >> 1) + 4 * (g4 & 1)] =
+                make_uint2(pack_bf16(X[4 * g4], X[4 * g4 + 1]), pack_bf16(X[4 * g4 + 2], X[4 * g4 + 3]));
     };
-    auto gemm_lds_reg = [&](f32x16 (&Xn)[NT], const unsigned short *Am, const bf16x8 (&Xp)[NT][2]) {
-#pragma unroll
-        for (int to = 0; to < NT; ++to) {
-            __builtin_amdgcn_sched_barrier(0);
-            f32x16 acc = zero16();
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
-                }
-            Xn[to] = acc;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // acc[to] += sum_i Am[j][i] * Bm[k][i]   (A rows j from LDS, B rows k = this lane's query from a global AT-format image)
-    auto gemm_lds_glob = [&](f32x16 (&acc)[NT], const unsigned short *Am, const unsigned short *Bm) {
-        const unsigned short *brow = Bm + (size_t)qi * LDA;
+    // one 32x32 output tile of (LDS image rows) . (packed slab):  acc += Am[32to + r][:] . Xp
+    auto gemm_tile = [&](f32x16 acc, const unsigned short *Am, int to, const bf16x8 (&Xp)[NT][2]) -> f32x16 {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 bfr = *(const bf16x8 *)&(brow + 8 * h)[32 * t + 16 * s];
-#pragma unroll
-                for (int to = 0; to < NT; ++to) {
-                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
-                    acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[to], 0, 0, 0);
-                }
+                const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
             }
+        return acc;
+    };
+    // Xn = Am . Xp for all output tiles, result re-packed (chain state never exists as an fp32 slab)
+    auto gemm_packed = [&](bf16x8 (&Xp)[NT][2], const unsigned short *Am) {
+        bf16x8 Xn[NT][2];
+#pragma unroll
+        for (int to = 0; to < NT; ++to) { const f32x16 acc = gemm_tile(zero16(), Am, to, Xp); pack_tile_bf(Xn[to][0], Xn[to][1], acc); }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
+    };
+    // uniform-index access to a packed slab inside rolled tile loops
+    auto pk_get = [&](const bf16x8 (&Xp)[NT][2], int t, bf16x8 &lo, bf16x8 &hi) {
+        lo = Xp[0][0]; hi = Xp[0][1];
+        switch (t) {
+#define MOPK_GP(K_) case K_: if (K_ < NT) { lo = Xp[K_ < NT ? K_ : 0][0]; hi = Xp[K_ < NT ? K_ : 0][1]; } break;
+            MOPK_GP(1) MOPK_GP(2) MOPK_GP(3) MOPK_GP(4) MOPK_GP(5) MOPK_GP(6)
+#undef MOPK_GP
+            default: break;
+        }
+    };
+    auto pk_set = [&](bf16x8 (&Xp)[NT][2], int t, bf16x8 lo, bf16x8 hi) {
+        switch (t) {
+#define MOPK_SP(K_) case K_: if (K_ < NT) { Xp[K_ < NT ? K_ : 0][0] = lo; Xp[K_ < NT ? K_ : 0][1] = hi; } break;
+            MOPK_SP(0) MOPK_SP(1) MOPK_SP(2) MOPK_SP(3) MOPK_SP(4) MOPK_SP(5) MOPK_SP(6)
+#undef MOPK_SP
+            default: break;
+        }
     };
     auto load_rows = [&](bf16x8 (&Bf)[NT][2], const unsigned short *Bm) {      // this lane's row of a global AT image (14 x 16 B)
         const unsigned short *brow = Bm + (size_t)qi * LDA + 8 * h;
@@ -356,17 +340,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int s = 0; s < 2; ++s) Bf[t][s] = *(const bf16x8 *)&brow[32 * t + 16 * s];
     };
-    auto gemm_lds_pre = [&](f32x16 (&acc)[NT], const unsigned short *Am, const bf16x8 (&Bf)[NT][2]) {   // acc[to] += Am rows . Bf
+    // Pk[to] (+)= Am rows . Bf   with the running sum kept as packed bf16 tiles
+    auto gemm_acc_packed = [&](bf16x8 (&Pk)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
 #pragma unroll
         for (int to = 0; to < NT; ++to) {
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const bf16x8 af = *(const bf16x8 *)&(Am + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
-                    acc[to] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Bf[t][s], acc[to], 0, 0, 0);
-                }
+            f32x16 acc = accumulate ? unpack_tile_bf(Pk[to][0], Pk[to][1]) : zero16();
+            acc = gemm_tile(acc, Am, to, Bf);
+            pack_tile_bf(Pk[to][0], Pk[to][1], acc);
         }
     };
     // barrier for LDS-only hand-offs: global loads / stores stay in flight across it (a __syncthreads() fence
@@ -409,19 +390,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     auto store_i_packed = [&](unsigned short *dst, const bf16x8 (&Xp)[NT][2]) {
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            bf16x8 lo = Xp[0][0], hi = Xp[0][1];
-            switch (t) {
-#define MOPK_GP(K_) case K_: if (K_ < NT) { lo = Xp[K_ < NT ? K_ : 0][0]; hi = Xp[K_ < NT ? K_ : 0][1]; } break;
-                MOPK_GP(1) MOPK_GP(2) MOPK_GP(3) MOPK_GP(4) MOPK_GP(5) MOPK_GP(6)
-#undef MOPK_GP
-                default: break;
-            }
+            bf16x8 lo, hi;
+            pk_get(Xp, t, lo, hi);
             store_i_tile(dst, t, lo, hi);
         }
-    };
-    auto pack_all = [&](bf16x8 (&Xp)[NT][2], const f32x16 (&X)[NT]) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) pack_tile_bf(Xp[t][0], Xp[t][1], X[t]);
     };
     auto slot_st = [&](int s, const bf16x8 (&Xp)[NT][2]) {
         __builtin_amdgcn_sched_barrier(0);
@@ -435,34 +407,28 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(p[(2 * t) * 64]); Xp[t][1] = as_b8(p[(2 * t + 1) * 64]); }
     };
-    auto log_means = [&](f32x16 (&X)[NT], float *rout) {   // X <- log(X+eps); row means; per-wave column partials
-        float rs = 0.f;
+    // log(C + eps) of one tile: row-sum, per-wave column partials (butterfly: 16 shuffles per tile)
+    auto log_tile = [&](f32x16 &X, int t, float &rs) {
+        float c[16];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
-            float c[16];
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const float v = __logf(X[t][g] + EPSC);
-                X[t][g] = v;
-                rs += (32 * t + tile_row(g, h) < N) ? v : 0.f;
-                c[g] = qok ? v : 0.f;
-            }
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int n = 8 >> st;
-                const bool up = (r >> (4 - st)) & 1;
-#pragma unroll
-                for (int k = 0; k < n; ++k) {
-                    const float keep = up ? c[k + n] : c[k], send = up ? c[k] : c[k + n];
-                    c[k] = keep + __shfl_xor(send, 16 >> st, 64);
-                }
-            }
-            c[0] += __shfl_xor(c[0], 1, 64);
-            if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
+        for (int g = 0; g < 16; ++g) {
+            const float v = __logf(X[g] + EPSC);
+            X[g] = v;
+            rs += (32 * t + tile_row(g, h) < N) ? v : 0.f;
+            c[g] = qok ? v : 0.f;
         }
-        rs += __shfl_xor(rs, 32, 64);
-        if (h == 0) rout[qi] = rs * invN;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int n = 8 >> st;
+            const bool up = (r >> (4 - st)) & 1;
+#pragma unroll
+            for (int k = 0; k < n; ++k) {
+                const float keep = up ? c[k + n] : c[k], send = up ? c[k] : c[k + n];
+                c[k] = keep + __shfl_xor(send, 16 >> st, 64);
+            }
+        }
+        c[0] += __shfl_xor(c[0], 1, 64);
+        if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
     };
     // copy the AT image staged in R to a global image with coalesced 16-byte accesses (all threads)
     auto export_R = [&](unsigned short *dst) {
@@ -470,50 +436,75 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         u32x4 *out = (u32x4 *)dst;
         for (int c = tid; c < NP * LDA / 8; c += NTH) out[c] = src[c];
     };
-    // forward chain recompute; every prefix product T_m (m = 0..V-2) is staged in R (AT format) and copied to Pg[m]
-    auto run_chain = [&](f32x16 (&X)[NT], bool forward, unsigned short *Pg) {
-        bf16x8 Xp[NT][2];
-        a_slab(X, forward ? 0 : V - 1);
+    // image of A_v (form ii) or A_v^T (form i) streamed tile by tile into dst (LDS)
+    auto a_image = [&](unsigned short *dst, int v, bool form_ii, bool have_stats) {
+        bf16x8 qe[KS];
+        make_frag(qe, qrow, sqk + v * DK);
+        float mx, inv;
+        if (have_stats) { mx = stats[(v * NP + qi) * 2]; inv = stats[(v * NP + qi) * 2 + 1]; }
+        else row_stats(qe, v, mx, inv);
+        lds_barrier();                    // previous readers of dst are done
+#pragma nounroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x16 A = a_tile(qe, t, mx, inv);
+            if (form_ii) store_ii_tile(dst, t, A);
+            else { bf16x8 lo, hi; pack_tile_bf(lo, hi, A); store_i_tile(dst, t, lo, hi); }
+        }
+        lds_barrier();
+    };
+    // forward chain recompute on packed state; every prefix product T_m (m = 0..V-2) is staged in R (AT format)
+    // and copied to Pg[m]; returns the final product in Xp
+    auto run_chain = [&](bf16x8 (&Xp)[NT][2], bool forward, unsigned short *Pg) {
+        {
+            const int v = forward ? 0 : V - 1;
+            bf16x8 qe[KS];
+            float mx, inv;
+            make_frag(qe, qrow, sqk + v * DK);
+            row_stats(qe, v, mx, inv);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, mx, inv); pack_tile_bf(Xp[t][0], Xp[t][1], A); }
+        }
         for (int m = 1; m < V; ++m) {
-            __syncthreads();                  // R free (previous GEMM / export readers done)
-            store_i(R, X);                    // T_{m-1}^T image
+            lds_barrier();                    // R free (previous GEMM / export readers done)
+            store_i_packed(R, Xp);            // T_{m-1}^T image
             __syncthreads();
             export_R(Pg + (size_t)(m - 1) * NP * LDA);
-            pack_all(Xp, X);
-            a_slab(X, forward ? m : V - 1 - m);
-            __syncthreads();
-            store_i(R, X);
-            __syncthreads();
-            gemm_lds_reg(X, R, Xp);
+            a_image(R, forward ? m : V - 1 - m, false, false);
+            gemm_packed(Xp, R);
         }
     };
+    // means of log(C + eps) from the packed product; optional packed fp16 copy of the log
+    auto log_means_packed = [&](const bf16x8 (&Xp)[NT][2], float *rout, unsigned int (*cr)[8]) {
+        float rs = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x16 c = unpack_tile_bf(Xp[t][0], Xp[t][1]);
+            log_tile(c, t, rs);
+            if (cr) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p) cr[t][p] = pack_h2(c[2 * p], c[2 * p + 1]);
+            }
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        if (h == 0) rout[qi] = rs * invN;
+    };
 
-    f32x16 X[NT];
     STAMP();
     REFRESH();
     // ================= P1/P2: forward chains (recompute) =================
     __syncthreads();                     // P0 global images + LDS complete
-    run_chain(X, false, Ug);
-    {
-        bf16x8 Xp[NT][2];
-        pack_all(Xp, X);
-        slot_st(S_CB, Xp);
-    }
-    log_means(X, rCl);
-    __syncthreads();
-    if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
-    run_chain(X, true, Tg);
-    {
-        bf16x8 Xp[NT][2];
-        pack_all(Xp, X);
-        slot_st(S_CF, Xp);
-    }
-    log_means(X, rCr);
     unsigned int crp[NT][8];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(X[t][2 * p], X[t][2 * p + 1]);
+    {
+        bf16x8 Xp[NT][2];
+        run_chain(Xp, false, Ug);
+        slot_st(S_CB, Xp);
+        log_means_packed(Xp, rCl, nullptr);
+        __syncthreads();
+        if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
+        run_chain(Xp, true, Tg);
+        slot_st(S_CF, Xp);
+        log_means_packed(Xp, rCr, crp);
+    }
     __syncthreads();
     if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
     __syncthreads();
@@ -909,38 +900,35 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     // ================= P9: <- chain backward: D'_m slabs parked in S_DL+m =================
     {
         const float drl = dmean[(2 * V + 2) * NP + qi];
+        bf16x8 Dp[NT][2];
         {
             bf16x8 Xp[NT][2];
             slot_ld(S_CB, Xp);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f32x16 cb = unpack_tile_bf(Xp[t][0], Xp[t][1]);
+                f32x16 d;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * t + tile_row(g, h);
-                    X[t][g] = (j < N && qok) ? (drl + dmean[(2 * V + 3) * NP + j]) / (cb[g] + EPSC) : 0.f;
+                    d[g] = (j < N && qok) ? (drl + dmean[(2 * V + 3) * NP + j]) / (cb[g] + EPSC) : 0.f;
                 }
+                pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
         }
         for (int m = V - 1; m >= 1; --m) {
-            bf16x8 Dp[NT][2];
-            pack_all(Dp, X);
             slot_st(S_DL + m, Dp);
-            a_slab(X, V - 1 - m);                      // A_av slab (rows = my queries)
-            lds_barrier();
-            store_ii(R, X);
-            lds_barrier();
-            gemm_lds_reg(X, R, Dp);                    // D'_{m-1}^T = A_av D'_m^T
+            a_image(R, V - 1 - m, true, true);         // A_av (rows = queries)
+            gemm_packed(Dp, R);                        // D'_{m-1}^T = A_av D'_m^T
         }
-        bf16x8 Dp[NT][2];
-        pack_all(Dp, X);
         slot_st(S_DL, Dp);
     }
     STAMP();
     REFRESH();
     // ================= P10: -> chain backward with per-view totals =================
     {
-        // dC->^T slab
+        // dC->^T slab, packed tile by tile
+        bf16x8 Dp[NT][2];
         {
             const float drr = dmean[(2 * V) * NP + qi];
             bf16x8 Cp[NT][2], C3[NT][2];
@@ -951,31 +939,30 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 const f32x16 cf = unpack_tile_bf(Cp[t][0], Cp[t][1]);
                 const f32x16 c3 = unpack_tile_bf(C3[t][0], C3[t][1]);
                 const f32x16 dyv = g_tile(VLs, dyf, t);          // (dy vL^T)^T tile
+                f32x16 d;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * t + tile_row(g, h);
-                    X[t][g] = (j < N && qok) ? (c3[g] + drr + dmean[(2 * V + 1) * NP + j]) / (cf[g] + EPSC) + wv * dyv[g] : 0.f;
+                    d[g] = (j < N && qok) ? (c3[g] + drr + dmean[(2 * V + 1) * NP + j]) / (cf[g] + EPSC) + wv * dyv[g] : 0.f;
                 }
+                pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
         }
-        bf16x8 Dp[NT][2];
-        pack_all(Dp, X);
         for (int v = V - 1; v >= 0; --v) {
             slot_st(S_DP, Dp);                         // park D_v (B operand of the D-chain step below)
             REFRESH();
-            // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index)
+            // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index), kept as packed bf16 tiles
+            bf16x8 dAp[NT][2];
             if (v >= 1) {
                 bf16x8 Bf[NT][2];
                 load_rows(Bf, Tg + (size_t)(v - 1) * NP * LDA);          // in flight across the barriers below
                 lds_barrier();
                 store_i_packed(R, Dp);
                 lds_barrier();
-#pragma unroll
-                for (int t = 0; t < NT; ++t) X[t] = zero16();
-                gemm_lds_pre(X, R, Bf);
+                gemm_acc_packed(dAp, R, Bf, false);
             } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) X[t] = unpack_tile_bf(Dp[t][0], Dp[t][1]);
+                for (int t = 0; t < NT; ++t) { dAp[t][0] = Dp[t][0]; dAp[t][1] = Dp[t][1]; }
             }
             {
                 const int mp = V - 1 - v;
@@ -987,24 +974,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     lds_barrier();
                     store_i_packed(R, Dl);
                     lds_barrier();
-                    gemm_lds_pre(X, R, Bf);
+                    gemm_acc_packed(dAp, R, Bf, true);
                 } else {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) X[t] += unpack_tile_bf(Dl[t][0], Dl[t][1]);
+                    for (int t = 0; t < NT; ++t) {
+                        f32x16 x = unpack_tile_bf(dAp[t][0], dAp[t][1]);
+                        x += unpack_tile_bf(Dl[t][0], Dl[t][1]);
+                        pack_tile_bf(dAp[t][0], dAp[t][1], x);
+                    }
                 }
             }
             if (v == V - 1) STAMP();
             REFRESH();
-            // ---- softmax backward + direct + mean terms -> dS_v^T.  The dA slab is parked (bf16) in this wave's
-            //      private 14 KB of the R region, which is idle between the dA GEMMs and the dS^T image: the tile
-            //      loops below stay rolled with the whole register file free (keeping dA in VGPRs made hipcc
-            //      spill ~8000 registers around the rolled loops).
-            lds_barrier();                                 // every wave is done reading the D images in R
-            unsigned short *dapark = R + (size_t)w * NT * 16 * 64 + lane;    // [(t*16+g)][lane]
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) dapark[(t * 16 + g) * 64] = f2bf(X[t][g]);
+            // ---- softmax backward + direct + mean terms -> dS_v^T (rolled tile loops; dA and dS live as packed tiles)
             bf16x8 Sp[NT][2];
             {
                 const float smx = stats[(v * NP + qi) * 2], sinv = stats[(v * NP + qi) * 2 + 1];
@@ -1014,8 +996,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x16 A = a_tile(qe, t, smx, sinv);
+                    bf16x8 dl_, dh_;
+                    pk_get(dAp, t, dl_, dh_);
+                    const f32x16 dA = unpack_tile_bf(dl_, dh_);
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], bf2f(dapark[(t * 16 + g) * 64]), dot);
+                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dA[g], dot);
                 }
                 dot += __shfl_xor(dot, 32, 64);
                 const float drs = dmean[v * NP + qi];
@@ -1045,21 +1030,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int g = 0; g < 16; ++g) pi[g] = fmaf(c2[g], pi[g], cd[g]);
                     }
+                    bf16x8 dl_, dh_;
+                    pk_get(dAp, t, dl_, dh_);
+                    const f32x16 dA = unpack_tile_bf(dl_, dh_);
                     f32x16 dS;
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * t + tile_row(g, h);
                         const float A = __expf(Sv[g] - smx) * sinv;
-                        dS[g] = j < N ? A * (bf2f(dapark[(t * 16 + g) * 64]) - dot) + pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
+                        dS[g] = j < N ? A * (dA[g] - dot) + pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
                     }
                     bf16x8 lo, hi;
                     pack_tile_bf(lo, hi, dS);
-                    switch (t) {   // uniform: keeps the packed slab in VGPRs with a rolled tile loop
-#define MOPK_SP(K_) case K_: if (K_ < NT) { Sp[K_ < NT ? K_ : 0][0] = lo; Sp[K_ < NT ? K_ : 0][1] = hi; } break;
-                        MOPK_SP(0) MOPK_SP(1) MOPK_SP(2) MOPK_SP(3) MOPK_SP(4) MOPK_SP(5) MOPK_SP(6)
-#undef MOPK_SP
-                        default: break;
-                    }
+                    pk_set(Sp, t, lo, hi);
                 }
             }
             if (v == V - 1) STAMP();
@@ -1132,12 +1115,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             // ---- D_{v-1}^T = A_v D_v^T
             if (v >= 1) {
                 slot_ld(S_DP, Dp);                 // issued early: consumed after the A_v image is staged
-                a_slab(X, v);
-                lds_barrier();
-                store_ii(R, X);
-                lds_barrier();
-                gemm_lds_reg(X, R, Dp);
-                pack_all(Dp, X);
+                a_image(R, v, true, true);
+                gemm_packed(Dp, R);
             }
         }
     }
