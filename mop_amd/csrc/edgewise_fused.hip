@@ -33,10 +33,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     unsigned short *bT = AT + 2 * DP * LDA;                        // [4][NP][BTS]
     unsigned short *Ksm = (unsigned short *)(smem + Cfg::R_BYTES); // [NP][LDK]
     float *fs = (float *)(smem + Cfg::R_BYTES + Cfg::K_BYTES);
-    float *sqk = fs, *qbar = sqk + 8 * DK, *kbar = qbar + DK, *vs0 = kbar + DK, *vsL = vs0 + DK;
+    float *sqk = fs, *sqk2 = sqk + 8 * DK, *qbar = sqk2 + 8 * DK, *kbar = qbar + DK, *vs0 = kbar + DK, *vsL = vs0 + DK;   // sqk2 = sqk * log2(e)
     float *rCr = vsL + DK, *rCl = rCr + NP, *cCr = rCl + NP, *cCl = cCr + NP;
     float *colpart = cCl + NP;                                     // [NT][NP]
     float *rS = colpart + NT * NP, *cS = rS + a.V * NP;            // [V][NP]
+    float *cst = rS;                                               // [V][NP] softmax constants c_v[i] = log2 sum_j 2^(S'_v[i,j]); aliases rS (dead until the gate phase)
     float *wsig = cS + a.V * NP;
 
     const int tid = threadIdx.x, w = tid >> 6;
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             if (j < N) v = load8_bf16<IOT>(kp + (int64_t)j * a.k.sn + dc * 8);
             *(bf16x8 *)&Ksm[j * LDK + dc * 8] = v;
         }
-        for (int c = tid; c < V * DK; c += NT * 64) sqk[c] = a.sqk[((c / DK) * H + hh) * DK + (c % DK)];
+        for (int c = tid; c < V * DK; c += NT * 64) { const float t = a.sqk[((c / DK) * H + hh) * DK + (c % DK)]; sqk[c] = t; sqk2[c] = t * 1.4426950408889634f; }
         for (int c = tid; c < DK; c += NT * 64) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
         if (tid == 0) wsig[0] = 1.f / (1.f + __expf(-*a.chain_logit));
     }
@@ -90,40 +91,24 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         kbar[tid] = sk * invN; qbar[tid] = sq * invN;
     }
     __syncthreads();
-    // row / col means of S_v are linear in q, k:  rS_v[i] = Qe_v[i,:].kbar ; cS_v[j] = k[j,:].(sqk_v*qbar)
-    for (int v = 0; v < V; ++v) {
-        float p = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = 16 * s + 8 * h + j;
-                p = fmaf(bf2f((unsigned short)qf[s][j]) * sqk[v * DK + d], kbar[d], p);
-            }
-        p += __shfl_xor(p, 32, 64);
-        if (h == 0) rS[v * NP + qi] = p;
-        if (tid < NP) {
-            float c = 0.f;
-            for (int d = 0; d < DK; ++d) c = fmaf(bf2f(Ksm[tid * LDK + d]) * sqk[v * DK + d], qbar[d], c);
-            cS[v * NP + tid] = c;
-        }
-    }
     }
 
     // ---------------- helpers ----------------
     const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
-    auto make_qe = [&](bf16x8 (&qe)[KS], int v) {   // Qe_v fragments; q re-read from L2 (keeps 16 VGPRs free)
+    auto make_qe_t = [&](bf16x8 (&qe)[KS], const float *tab, int v) {   // Qe_v fragments; q re-read from L2 (keeps 16 VGPRs free)
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             bf16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (qok) qv = load8_bf16<IOT>(qrow + 16 * s + 8 * h);
-            const float4 s0 = *(const float4 *)&sqk[v * DK + 16 * s + 8 * h];
-            const float4 s1 = *(const float4 *)&sqk[v * DK + 16 * s + 8 * h + 4];
+            const float4 s0 = *(const float4 *)&tab[v * DK + 16 * s + 8 * h];
+            const float4 s1 = *(const float4 *)&tab[v * DK + 16 * s + 8 * h + 4];
             const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
             for (int j = 0; j < 8; ++j) qe[s][j] = (short)f2bf(bf2f((unsigned short)qv[j]) * sc[j]);
         }
     };
+    auto make_qe = [&](bf16x8 (&qe)[KS], int v) { make_qe_t(qe, sqk, v); };      // natural scores (mix)
+    auto make_qe2 = [&](bf16x8 (&qe)[KS], int v) { make_qe_t(qe, sqk2, v); };    // scores * log2(e) (softmax slabs: exp2, no multiply)
     auto s_tile = [&](const bf16x8 (&qe)[KS], int t) -> f32x16 {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -136,30 +121,40 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     // ---- tile-streamed primitives: no N x 32 fp32 slab is ever held in registers; chain state lives as packed
     //      bf16 B-operand fragments (8 VGPRs per 32x32 tile), accumulators are consumed tile by tile.
     constexpr float NEG = -1e30f;                     // finite "-inf" (keeps the online softmax NaN-free)
-    // row statistics of softmax_j S_v[i, j] for this lane's query, online over key tiles   :500-507
-    auto row_stats = [&](const bf16x8 (&qe)[KS], float &mx, float &inv) {
+    // softmax constant of this lane's query for view v, online over key tiles (scores pre-scaled by log2 e):
+    //   c = log2 sum_j 2^(S'[i,j])   ->   A_v[i,j] = 2^(S'[i,j] - c)                                  :500-507
+    // only tiles that contain keys >= N pay for the mask
+    auto row_const = [&](const bf16x8 (&qe)[KS]) -> float {
         float m = NEG, l = 0.f;
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
             f32x16 S = s_tile(qe, t);
+            if (32 * t + 32 > N) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) if (32 * t + tile_row(g, h) >= N) S[g] = NEG;
+            }
             float tm = NEG;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { if (32 * t + tile_row(g, h) >= N) S[g] = NEG; tm = fmaxf(tm, S[g]); }
+            for (int g = 0; g < 16; ++g) tm = fmaxf(tm, S[g]);
             const float mn = fmaxf(m, tm);
             float sm = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) sm += __expf(S[g] - mn);
-            l = fmaf(l, __expf(m - mn), sm);
+            for (int g = 0; g < 16; ++g) sm += __builtin_amdgcn_exp2f(S[g] - mn);
+            l = fmaf(l, __builtin_amdgcn_exp2f(m - mn), sm);
             m = mn;
         }
         const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
-        mx = fmaxf(m, m2);
-        inv = 1.f / (l * __expf(m - mx) + l2 * __expf(m2 - mx));
+        const float mx = fmaxf(m, m2);
+        return mx + __builtin_amdgcn_logf(l * __builtin_amdgcn_exp2f(m - mx) + l2 * __builtin_amdgcn_exp2f(m2 - mx));
     };
-    auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float mx, float inv) -> f32x16 {   // A_v^T tile (masked rows -> 0)
+    auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float c) -> f32x16 {   // A_v^T tile (keys >= N -> 0)
         f32x16 S = s_tile(qe, t);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) S[g] = (32 * t + tile_row(g, h) < N) ? __expf(S[g] - mx) * inv : 0.f;
+        for (int g = 0; g < 16; ++g) S[g] = __builtin_amdgcn_exp2f(S[g] - c);
+        if (32 * t + 32 > N) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) if (32 * t + tile_row(g, h) >= N) S[g] = 0.f;
+        }
         return S;
     };
     auto pack_tile = [&](bf16x8 &lo, bf16x8 &hi, const f32x16 &x) {
@@ -213,24 +208,31 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     // the last step hands every fp32 output tile to `epi(to, acc)`
     auto run_chain = [&](bool forward, auto &&epi) {
         bf16x8 Xp[NT][2];
+        // the <- chain (run first) computes every view's softmax constant once and parks it in LDS for the -> chain
+        auto view_const = [&](const bf16x8 (&qe)[KS], int v) -> float {
+            if (forward) return cst[v * NP + qi];
+            const float c = row_const(qe);
+            if (h == 0) cst[v * NP + qi] = c;
+            return c;
+        };
         {
+            const int v = forward ? 0 : V - 1;
             bf16x8 qe[KS];
-            float mx, inv;
-            make_qe(qe, forward ? 0 : V - 1);
-            row_stats(qe, mx, inv);
+            make_qe2(qe, v);
+            const float c = view_const(qe, v);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, mx, inv); pack_tile(Xp[t][0], Xp[t][1], A); }
+            for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, c); pack_tile(Xp[t][0], Xp[t][1], A); }
         }
         for (int m = 1; m < V; ++m) {
             {
+                const int v = forward ? m : V - 1 - m;
                 bf16x8 qe[KS];
-                float mx, inv;
-                make_qe(qe, forward ? m : V - 1 - m);
-                row_stats(qe, mx, inv);
+                make_qe2(qe, v);
+                const float c = view_const(qe, v);
                 __syncthreads();              // previous step's readers of AT are done
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x16 A = a_tile(qe, t, mx, inv);
+                    const f32x16 A = a_tile(qe, t, c);
                     bf16x8 lo, hi;
                     pack_tile(lo, hi, A);
                     store_AT_tile(t, lo, hi);
@@ -300,8 +302,32 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             }
             if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NT * 64) { VT0[DK * LDA + c] = 0; VTL[DK * LDA + c] = 0; }
             if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
+            // row / col means of S_v are linear in q, k:  rS_v[i] = Qe_v[i,:].kbar ; cS_v[j] = k[j,:].(sqk_v*qbar)
+            // (written over the softmax constants `cst`, which the chains no longer need)
+            {
+                bf16x8 qf[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(qrow + 16 * s + 8 * h); qf[s] = v; }
+                for (int v = 0; v < V; ++v) {
+                    float p = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int d = 16 * s + 8 * h + j;
+                            p = fmaf(bf2f((unsigned short)qf[s][j]) * sqk[v * DK + d], kbar[d], p);
+                        }
+                    p += __shfl_xor(p, 32, 64);
+                    if (h == 0) rS[v * NP + qi] = p;
+                    if (tid < NP) {
+                        float c = 0.f;
+                        for (int d = 0; d < DK; ++d) c = fmaf(bf2f(Ksm[tid * LDK + d]) * sqk[v * DK + d], qbar[d], c);
+                        cS[v * NP + tid] = c;
+                    }
+                }
+            }
         }
-        __syncthreads();                      // VT*, cCr complete
+        __syncthreads();                      // VT*, cCr, rS, cS complete
         const float wv = wsig[0];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {     // y_chain^T = VL^T C->^T       :556-560 (as C-> vL); parked in `saved`
@@ -358,7 +384,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned short hi = f2bf(av[k]), lo = f2bf(av[k] - bf2f(hi));
+            const float a2 = av[k] * 1.4426950408889634f;               // gate logits come out pre-scaled by log2(e): sigmoid = 1/(1+2^-z')
+            const unsigned short hi = f2bf(a2), lo = f2bf(a2 - bf2f(hi));
             af4[g][k] = (short)hi;                          // h=0: slots 0-3 a_hi ; h=1: slots 8-11 a_hi
             af4[g][4 + k] = h == 0 ? (short)lo : (short)0;  // h=0: slots 4-7 a_lo ; h=1: slots 12-15 0
         }
@@ -373,7 +400,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         const bf16x8 bfrag = *(const bf16x8 *)&bT[(g4 * NP + 32 * t + r) * BTS + 8 * h];
         f32x16 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, af4[g4], z0, 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) z[g] = 1.f / (1.f + __expf(-z[g]));
+        for (int g = 0; g < 16; ++g) z[g] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z[g]));
         return z;
     };
     // runtime loop over key tiles (an unrolled one makes hipcc overlap the tiles' live ranges and

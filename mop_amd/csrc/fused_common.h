@@ -17,9 +17,9 @@ struct FusedCfg {
     static constexpr int DT = DK >= 32 ? DK / 32 : 1, DP = DT * 32;
     static constexpr int R_BYTES = imax(NP * LDA * 2, 2 * DP * LDA * 2 + 4 * NP * BTS * 2);
     static constexpr int K_BYTES = NP * LDK * 2;
-    // fp32 scratch (floats): sqk[8][DK] qbar kbar vs0 vsL [DK] | rCr rCl cCr cCl [NP] | colpart[NT][NP] | rS cS [V][NP] | wsig
+    // fp32 scratch (floats): sqk sqk2 [8][DK] qbar kbar vs0 vsL [DK] | rCr rCl cCr cCl [NP] | colpart[NT][NP] | rS cS cst [V][NP] | wsig
     static __host__ __device__ constexpr int small_floats(int V) {
-        return 8 * DK + 4 * DK + 4 * NP + NT * NP + 2 * V * NP + 8;
+        return 16 * DK + 4 * DK + 4 * NP + NT * NP + 2 * V * NP + 8;
     }
     static __host__ __device__ constexpr int lds_bytes(int V) { return R_BYTES + K_BYTES + 4 * small_floats(V); }
 };
