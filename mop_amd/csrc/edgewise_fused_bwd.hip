@@ -57,7 +57,7 @@ struct BwdCfg {
     static constexpr int K_BYTES = F::K_BYTES;
     static __host__ __device__ constexpr int small_floats(int V) {
         // sqk[8][DK] qbar kbar vs0 vsL | rCr rCl cCr cCl | colpart[NT][NP] | rS cS [V][NP] (later: dmean[2V+4][NP]) | misc
-        return 8 * DK + 4 * DK + 4 * NP + NT * NP + imax(2 * V * NP, (2 * V + 4) * NP - NT * NP) + 2 * NT * DK + 16;
+        return 16 * DK + 4 * DK + 4 * NP + NT * NP + imax(2 * V * NP, (2 * V + 4) * NP - NT * NP) + 2 * NT * DK + 16;
     }
     static __host__ __device__ constexpr int lds_bytes(int V) { return R_BYTES + K_BYTES + 4 * small_floats(V); }
 };
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     float *dbv = dav + 16 * NP;                                       // [16][NP]
     unsigned short *Ksm = (unsigned short *)(smem + Cfg::R_BYTES);    // [NP][LDK]
     float *fs = (float *)(smem + Cfg::R_BYTES + Cfg::K_BYTES);
-    float *sqk = fs, *qbar = sqk + 8 * DK, *kbar = qbar + DK, *vs0 = kbar + DK, *vsL = vs0 + DK;
+    float *sqk = fs, *sqk2 = sqk + 8 * DK, *qbar = sqk2 + 8 * DK, *kbar = qbar + DK, *vs0 = kbar + DK, *vsL = vs0 + DK;   // sqk2 = sqk * log2(e)
     float *rCr = vsL + DK, *rCl = rCr + NP, *cCr = rCl + NP, *cCl = cCr + NP;
     float *colpart = cCl + NP;                                        // [NT][NP]
     float *rS = colpart + NT * NP, *cS = rS + a.V * NP;               // [V][NP]
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     unsigned short *Tg = (unsigned short *)(ws + W.oT), *Ug = (unsigned short *)(ws + W.oU);
     unsigned short *KT = (unsigned short *)(ws + W.oKT), *QT = (unsigned short *)(ws + W.oQT), *DYT = (unsigned short *)(ws + W.oDYT);
     unsigned short *V0s = (unsigned short *)(ws + W.oV0s), *VLs = (unsigned short *)(ws + W.oVLs);
-    float *stats = (float *)(ws + W.oStats);                          // [V][NP][2]  (row max, 1/row sum)
+    float *stats = (float *)(ws + W.oStats);                          // [V][NP] softmax constants c_v[i] (log2 of the row sum of 2^S')
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
     float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)a.V * NT * DT * 16 * 64;   // [V][NT][DT*16][64]
     float *dwp = (float *)(ws + W.oDW);
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         const IOT *dp = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh;
         const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
         const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
-        for (int c = tid; c < V * DK; c += NTH) sqk[c] = a.sqk[((c / DK) * H + hh) * DK + (c % DK)];
+        for (int c = tid; c < V * DK; c += NTH) { const float t = a.sqk[((c / DK) * H + hh) * DK + (c % DK)]; sqk[c] = t; sqk2[c] = t * 1.4426950408889634f; }
         for (int c = tid; c < DK; c += NTH) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
         if (tid == 0) misc[0] = 1.f / (1.f + __expf(-*a.chain_logit));
         constexpr int CH = DK / 8;
@@ -253,32 +253,42 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         return acc;
     };
     constexpr float NEG = -1e30f;                     // finite "-inf" (keeps the online softmax NaN-free)
-    // row statistics of softmax_j S_v[i, :] for this lane's query, online over key tiles; parked in `stats`
-    auto row_stats = [&](const bf16x8 (&qe)[KS], int v, float &mx, float &inv) {
+    // softmax constant of this lane's query for view v (scores pre-scaled by log2 e), online over key tiles:
+    //   c = log2 sum_j 2^(S'[i,j])  ->  A_v[i,j] = 2^(S'[i,j] - c);  parked in `stats`; only tail tiles pay for the mask
+    auto row_const = [&](const bf16x8 (&qe)[KS], int v) -> float {
         float m = NEG, l = 0.f;
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
             f32x16 S = s_tile(qe, t);
+            if (32 * t + 32 > N) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) if (32 * t + tile_row(g, h) >= N) S[g] = NEG;
+            }
             float tm = NEG;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) { if (32 * t + tile_row(g, h) >= N) S[g] = NEG; tm = fmaxf(tm, S[g]); }
+            for (int g = 0; g < 16; ++g) tm = fmaxf(tm, S[g]);
             const float mn = fmaxf(m, tm);
             float sm = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) sm += __expf(S[g] - mn);
-            l = fmaf(l, __expf(m - mn), sm);
+            for (int g = 0; g < 16; ++g) sm += __builtin_amdgcn_exp2f(S[g] - mn);
+            l = fmaf(l, __builtin_amdgcn_exp2f(m - mn), sm);
             m = mn;
         }
         const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
-        mx = fmaxf(m, m2);
-        inv = 1.f / (l * __expf(m - mx) + l2 * __expf(m2 - mx));
-        if (h == 0) { stats[(v * NP + qi) * 2] = mx; stats[(v * NP + qi) * 2 + 1] = inv; }
+        const float mx = fmaxf(m, m2);
+        const float c = mx + __builtin_amdgcn_logf(l * __builtin_amdgcn_exp2f(m - mx) + l2 * __builtin_amdgcn_exp2f(m2 - mx));
+        if (h == 0) stats[v * NP + qi] = c;
+        return c;
     };
-    auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float mx, float inv) -> f32x16 {   // one tile of A_v^T from saved stats
-        f32x16 s = s_tile(qe, t);
+    auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float c) -> f32x16 {   // one tile of A_v^T (keys >= N -> 0)
+        f32x16 S = s_tile(qe, t);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) s[g] = (32 * t + tile_row(g, h) < N) ? __expf(s[g] - mx) * inv : 0.f;
-        return s;
+        for (int g = 0; g < 16; ++g) S[g] = __builtin_amdgcn_exp2f(S[g] - c);
+        if (32 * t + 32 > N) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) if (32 * t + tile_row(g, h) >= N) S[g] = 0.f;
+        }
+        return S;
     };
     // form (i): dst[j][perm(i)] = X^T tile (A operand for products contracting over QUERIES)
     auto store_i_tile = [&](unsigned short *dst, int t, bf16x8 lo, bf16x8 hi) {
@@ -439,14 +449,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     // image of A_v (form ii) or A_v^T (form i) streamed tile by tile into dst (LDS)
     auto a_image = [&](unsigned short *dst, int v, bool form_ii, bool have_stats) {
         bf16x8 qe[KS];
-        make_frag(qe, qrow, sqk + v * DK);
-        float mx, inv;
-        if (have_stats) { mx = stats[(v * NP + qi) * 2]; inv = stats[(v * NP + qi) * 2 + 1]; }
-        else row_stats(qe, v, mx, inv);
+        make_frag(qe, qrow, sqk2 + v * DK);
+        const float c = have_stats ? stats[v * NP + qi] : row_const(qe, v);
         lds_barrier();                    // previous readers of dst are done
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            const f32x16 A = a_tile(qe, t, mx, inv);
+            const f32x16 A = a_tile(qe, t, c);
             if (form_ii) store_ii_tile(dst, t, A);
             else { bf16x8 lo, hi; pack_tile_bf(lo, hi, A); store_i_tile(dst, t, lo, hi); }
         }
@@ -458,18 +466,17 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         {
             const int v = forward ? 0 : V - 1;
             bf16x8 qe[KS];
-            float mx, inv;
-            make_frag(qe, qrow, sqk + v * DK);
-            row_stats(qe, v, mx, inv);
+            make_frag(qe, qrow, sqk2 + v * DK);
+            const float c = forward ? stats[v * NP + qi] : row_const(qe, v);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, mx, inv); pack_tile_bf(Xp[t][0], Xp[t][1], A); }
+            for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, c); pack_tile_bf(Xp[t][0], Xp[t][1], A); }
         }
         for (int m = 1; m < V; ++m) {
             lds_barrier();                    // R free (previous GEMM / export readers done)
             store_i_packed(R, Xp);            // T_{m-1}^T image
             __syncthreads();
             export_R(Pg + (size_t)(m - 1) * NP * LDA);
-            a_image(R, forward ? m : V - 1 - m, false, false);
+            a_image(R, forward ? m : V - 1 - m, false, forward);   // the <- chain (run first) computed every view's constant
             gemm_packed(Xp, R);
         }
     };
@@ -550,8 +557,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned short hi = f2bf(av[k]), lo = f2bf(av[k] - bf2f(hi));
-            af4[g][k] = (short)hi;
-            af4[g][4 + k] = h == 0 ? (short)lo : (short)0;
+            const float a2 = av[k] * 1.4426950408889634f;           // Z MFMA operand pre-scaled: sigmoid = 1/(1+2^-z')
+            const unsigned short hi2 = f2bf(a2), lo2 = f2bf(a2 - bf2f(hi2));
+            af4[g][k] = (short)hi2;
+            af4[g][4 + k] = h == 0 ? (short)lo2 : (short)0;
             if (h == 0) { amat[(4 * g + k) * LDA + qi] = qok ? hi : (unsigned short)0; amat[(16 + 4 * g + k) * LDA + qi] = qok ? lo : (unsigned short)0; }
         }
     }
@@ -564,7 +573,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         const bf16x8 bfrag = *(const bf16x8 *)&bT[(g4 * NP + 32 * t + r) * BTS + 8 * h];
         f32x16 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, af4[g4], zero16(), 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) z[g] = 1.f / (1.f + __expf(-z[g]));
+        for (int g = 0; g < 16; ++g) z[g] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z[g]));
         return z;
     };
     auto crp_get = [&](unsigned int (&cw)[8], int t) {
@@ -612,7 +621,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
         {
             u32x4 lo, hi;
-            pack_tile_h(lo, hi, L);
+            pack_tile_h(lo, hi, L * 1.4426950408889634f);            // parked as L * log2(e): the dS pass works in base 2
             u32x4 *p = slot(S_L);
             p[(2 * t) * 64] = lo; p[(2 * t + 1) * 64] = hi;
         }
@@ -695,7 +704,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         f32x16 L, Cr;
         {
             const u32x4 *p = slot(S_L);
-            L = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);
+            L = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]) * 0.6931471805599453f;
             const u32x4 *pc = slot(S_CF);
             Cr = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
 #pragma unroll
@@ -989,13 +998,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             // ---- softmax backward + direct + mean terms -> dS_v^T (rolled tile loops; dA and dS live as packed tiles)
             bf16x8 Sp[NT][2];
             {
-                const float smx = stats[(v * NP + qi) * 2], sinv = stats[(v * NP + qi) * 2 + 1];
+                const float cv = stats[v * NP + qi];
                 bf16x8 qe[KS];
-                make_frag(qe, qrow, sqk + v * DK);
+                make_frag(qe, qrow, sqk2 + v * DK);       // base-2 scores: A = 2^(S' - c), pi = 2^(S'_v - S'_0 - L')
                 float dot = 0.f;
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x16 A = a_tile(qe, t, smx, sinv);
+                    const f32x16 A = a_tile(qe, t, cv);
                     bf16x8 dl_, dh_;
                     pk_get(dAp, t, dl_, dh_);
                     const f32x16 dA = unpack_tile_bf(dl_, dh_);
@@ -1005,7 +1014,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 dot += __shfl_xor(dot, 32, 64);
                 const float drs = dmean[v * NP + qi];
                 bf16x8 qe0[KS];
-                if (v != 0) make_frag(qe0, qrow, sqk);
+                if (v != 0) make_frag(qe0, qrow, sqk2);
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x16 Sv = s_tile(qe, t);
@@ -1016,10 +1025,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         if (v != 0) {
                             const f32x16 S0 = s_tile(qe0, t);
 #pragma unroll
-                            for (int g = 0; g < 16; ++g) pi[g] = __expf(Sv[g] - S0[g] - pi[g]);
+                            for (int g = 0; g < 16; ++g) pi[g] = __builtin_amdgcn_exp2f(Sv[g] - S0[g] - pi[g]);
                         } else {
 #pragma unroll
-                            for (int g = 0; g < 16; ++g) pi[g] = __expf(-pi[g]);
+                            for (int g = 0; g < 16; ++g) pi[g] = __builtin_amdgcn_exp2f(-pi[g]);
                         }
                     }
                     {
@@ -1037,7 +1046,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * t + tile_row(g, h);
-                        const float A = __expf(Sv[g] - smx) * sinv;
+                        const float A = __builtin_amdgcn_exp2f(Sv[g] - cv);
                         dS[g] = j < N ? A * (dA[g] - dot) + pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
                     }
                     bf16x8 lo, hi;
