@@ -542,6 +542,16 @@ MOPK_DECL(1, 16) MOPK_DECL(1, 32) MOPK_DECL(1, 64) MOPK_DECL(2, 16) MOPK_DECL(2,
 MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
 #undef MOPK_DECL
 static int pick_nt(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
+int ew_fused_bwd_lds_bytes(int nt, int dk, int V);
+template <int NT, int DK> static int lds_fwd(int V) { return FusedCfg<NT, DK>::lds_bytes(V); }
+static int ew_fused_lds_bytes(int nt, int dk, int V) {
+    int f = 1 << 30;
+#define MOPK_L(NT_) (dk == 16 ? lds_fwd<NT_, 16>(V) : dk == 32 ? lds_fwd<NT_, 32>(V) : lds_fwd<NT_, 64>(V))
+    switch (nt) { case 1: f = MOPK_L(1); break; case 2: f = MOPK_L(2); break; case 4: f = MOPK_L(4); break; case 7: f = MOPK_L(7); break; default: break; }
+#undef MOPK_L
+    const int bw = ew_fused_bwd_lds_bytes(nt, dk, V);
+    return f > bw ? f : bw;
+}
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
@@ -550,6 +560,7 @@ int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
     if (pick_nt(a->N) == 0) return 0;
     if (a->dk != 16 && a->dk != 32 && a->dk != 64) return 0;
     if (a->V < 2 || a->V > 8 || a->r < 1 || a->r > 4) return 0;
+    if (ew_fused_lds_bytes(pick_nt(a->N), a->dk, a->V) > 160 * 1024) return 0;   // forward AND backward must fit
     const int es = a->io_dtype == MOPK_BF16 ? 2 : 4;
     const int64_t al = 16 / es;                               // vector loads: 8 (bf16) / 4 (fp32) element alignment
     const MopkView4 vs[3] = {a->v0, a->vL, a->y};

@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dl = fmaf(bf2f((unsigned short)dyf[s][j]), ych[(size_t)qi * DK + 16 * s + 8 * h + j], dl);
+                for (int j = 0; j < 8; ++j) dl = fmaf(ld_as_f32(dyrow + 16 * s + 8 * h + j), ych[(size_t)qi * DK + 16 * s + 8 * h + j], dl);   // full-precision dy
         }
         dl = wave_sum(dl);
         if (lane == 0) misc[4 + w] = dl;
@@ -1239,6 +1239,12 @@ static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : 
         case 4: switch (a->dk) { case 16: return PFX##nt4_dk16(__VA_ARGS__); case 32: return PFX##nt4_dk32(__VA_ARGS__); default: return PFX##nt4_dk64(__VA_ARGS__); } \
         default: switch (a->dk) { case 16: return PFX##nt7_dk16(__VA_ARGS__); case 32: return PFX##nt7_dk32(__VA_ARGS__); default: return PFX##nt7_dk64(__VA_ARGS__); } \
     }
+template <int NT, int DK> static int lds_bwd(int V) { return BwdCfg<NT, DK>::lds_bytes(V); }
+int ew_fused_bwd_lds_bytes(int nt, int dk, int V) {
+#define MOPK_L(NT_) (dk == 16 ? lds_bwd<NT_, 16>(V) : dk == 32 ? lds_bwd<NT_, 32>(V) : lds_bwd<NT_, 64>(V))
+    switch (nt) { case 1: return MOPK_L(1); case 2: return MOPK_L(2); case 4: return MOPK_L(4); case 7: return MOPK_L(7); default: return 1 << 30; }
+#undef MOPK_L
+}
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {
     if (!ew_fused_fwd_supported(a)) return 0;
     if (a->dq.sv != 0 || a->dk_.sv != 0) return 0;

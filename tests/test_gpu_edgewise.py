@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import golden_names, load_golden
-from gpu_util import max_abs, module_from_golden, rel_err, run_fwd_bwd
+from gpu_util import check_grads, max_abs, module_from_golden, rel_err, run_fwd_bwd
 
 pytestmark = pytest.mark.gpu
 
@@ -134,3 +134,157 @@ def test_fused_forward_vs_reference_golden(name, dtype):
     err = max_abs(y.float().cpu().numpy(), d["y"])
     print(f"{name} {dtype}: fused fwd max-abs err {err:.3e}")
     assert err <= TOL_BF16, f"fused fwd y max-abs {err:.3e}"
+
+
+# ----------------------------------------------------------------------------------------------
+# fused gfx950 kernels: shape sweep vs the oracle, and size-independent properties at the full
+# BASELINE.json size (B=256, N=197, D=384, H=6, V=5, r=4)
+# ----------------------------------------------------------------------------------------------
+def _mk(D, H, V, r, seed, init="mix5"):
+    from mop_amd.nn import EdgewiseMSA
+    torch.manual_seed(seed)
+    m = EdgewiseMSA(D, H, n_views=V, share_qkv=True, gate_mode="lowrank", gate_rank=r, gate_init=init)
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("_scale"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif "edge_head" in n_ and n_.endswith("weight"):
+                p.mul_(3.0)
+        m.chain_value_logit.fill_(-0.5)
+    return m
+
+
+@pytest.mark.parametrize("shape", [
+    # B, N, D, H, V, r        (dk = D/H in {16, 32, 64}; N hits every NT bucket and its edges)
+    (2, 1, 32, 2, 2, 1), (3, 31, 64, 4, 3, 2), (2, 32, 64, 2, 5, 4), (2, 33, 128, 2, 2, 3), (1, 64, 64, 1, 8, 4),
+    (2, 65, 96, 3, 4, 2), (1, 128, 64, 4, 5, 4), (1, 129, 128, 2, 3, 1), (2, 196, 128, 2, 5, 4), (1, 224, 64, 1, 5, 4), (2, 100, 64, 1, 8, 4)])
+def test_fused_vs_oracle_shape_sweep(shape):
+    """fused fwd+bwd (bf16 MFMA) vs the float64 oracle on fresh seeded inputs."""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd import ops, _lib
+    B, N, D, H, V, r = shape
+    mop_amd.set_precision("bf16")
+    m = _mk(D, H, V, r, seed=B * 1000 + N)
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, N, D, generator=g).numpy()
+    w = torch.randn(B, N, D, generator=g).numpy()
+    out, cache = oe.module_fwd(x.astype(np.float64), params, H, V, True, 0.5)
+    dx_ref, g_ref = oe.module_bwd(w.astype(np.float64), cache)
+    y, dx, grads = run_fwd_bwd(m.cuda().eval(), x, w)
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED and ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_FUSED
+    assert max_abs(y, out) <= TOL_BF16
+    assert rel_err(dx, dx_ref) <= 5e-2
+    check_grads(grads, g_ref, GTOL_BF16, scalar_tol=0.5)
+
+
+def test_shapes_outside_the_fused_kernels_take_the_generic_path():
+    import mop_amd
+    from mop_amd import ops, _lib
+    mop_amd.set_precision("bf16")
+    m = _mk(64, 2, 3, 2, seed=5).cuda().eval()
+    x = torch.randn(1, 225, 64, device="cuda", requires_grad=True)      # N > 224
+    m(x).sum().backward()
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_GENERIC and ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_GENERIC
+    m3 = _mk(64, 1, 8, 4, seed=7).cuda().eval()                           # V = 8 at N = 224: LDS budget of the fused backward exceeded
+    x3 = torch.randn(1, 224, 64, device="cuda", requires_grad=True)
+    m3(x3).sum().backward()
+    assert ops.LAST_PATH["edgewise_fwd"] == ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_GENERIC
+    m2 = _mk(96, 2, 3, 2, seed=6).cuda().eval()                           # dk = 48
+    m2(torch.randn(1, 16, 96, device="cuda"))
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_GENERIC
+
+
+@pytest.fixture(scope="module")
+def ns_full():
+    """one fwd+bwd of the full BASELINE.json configs[1] size through the fused kernels (bf16)."""
+    import mop_amd
+    mop_amd.set_precision("auto")
+    m = _mk(384, 6, 5, 4, seed=0).cuda().to(torch.bfloat16).eval()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn(256, 197, 384, device="cuda", dtype=torch.bfloat16, generator=g)
+    dy = torch.randn(256, 197, 384, device="cuda", dtype=torch.bfloat16, generator=g)
+
+    def run(xx, dd):
+        m.zero_grad()
+        xx = xx.clone().requires_grad_(True)
+        y = m(xx)
+        y.backward(dd)
+        torch.cuda.synchronize()
+        return y.detach(), xx.grad.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    return m, x, dy, run
+
+
+def test_full_size_is_deterministic_and_batch_independent(ns_full):
+    """bit-identical across runs, and a sample's result does not depend on the batch it rides in
+    (every (b,h) is one workgroup with a fixed reduction order)."""
+    from mop_amd import ops, _lib
+    m, x, dy, run = ns_full
+    y1, dx1, g1 = run(x, dy)
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED and ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_FUSED
+    y2, dx2, g2 = run(x, dy)
+    assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    assert torch.isfinite(y1.float()).all() and torch.isfinite(dx1.float()).all()
+    # batch independence, checked on the attention core itself (the surrounding hipBLASLt GEMMs may pick a
+    # different tiling, hence summation order, for a different batch size)
+    H, dk, V = 6, 64, 5
+    g = torch.Generator(device="cuda").manual_seed(11)
+    qkv = torch.randn(256, 197, 1, 3, H, dk, device="cuda", dtype=torch.bfloat16, generator=g)
+    gy = torch.randn(256, 197, H * dk, device="cuda", dtype=torch.bfloat16, generator=g)
+    eh = m.edge_head
+
+    def core(q):
+        q = q.clone().requires_grad_(True)
+        sqk = (m.q_scale * m.k_scale).squeeze(2).float() / 8.0
+        y = ops.edgewise_lowrank_core(q, sqk, m.v_scale[0, :, 0].float(), m.v_scale[V - 1, :, 0].float(),
+                                      eh.row_proj.weight.squeeze(-1).float(), eh.row_proj.bias.float(),
+                                      eh.col_proj.weight.squeeze(-1).float(), eh.col_proj.bias.float(),
+                                      m.chain_value_logit.float(), 0.5, V)
+        y.backward(gy[: q.shape[0]] if q.shape[0] == 256 else gy[37:40])
+        return y.detach(), q.grad.detach()
+    yb, gb = core(qkv)
+    ys, gs = core(qkv[37:40])
+    assert torch.equal(ys, yb[37:40]) and torch.equal(gs, gb[37:40])
+
+
+def test_full_size_token_permutation_equivariance(ns_full):
+    """no positional term anywhere on the path: permuting the tokens permutes y and dx."""
+    m, x, dy, run = ns_full
+    perm = torch.randperm(197, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    y, dx, _ = run(x[:4], dy[:4])
+    yp, dxp, _ = run(x[:4][:, perm], dy[:4][:, perm])
+    assert max_abs(yp.float().cpu().numpy(), y[:, perm].float().cpu().numpy()) <= 2e-2
+    assert rel_err(dxp.float().cpu().numpy(), dx[:, perm].float().cpu().numpy()) <= 5e-2
+
+
+def test_full_size_gradient_linearity(ns_full):
+    """backward is linear in dy: grad(2 dy) == 2 grad(dy) (exactly, powers of two commute with rounding)."""
+    m, x, dy, run = ns_full
+    _, dx1, g1 = run(x[:8], dy[:8])
+    _, dx2, g2 = run(x[:8], 2 * dy[:8])
+    assert torch.equal(dx2, 2 * dx1)
+    for k in g1:
+        assert torch.equal(g2[k], 2 * g1[k]), k
+
+
+def test_constant_values_give_constant_rows():
+    """every attention map on the path is row-stochastic: with v_j = c for all tokens,
+    y_i = c*vs0 + sigmoid(w) * c*vsL for every query (reference :554-562)."""
+    import mop_amd
+    mop_amd.set_precision("bf16")
+    D, H, V = 128, 2, 5
+    m = _mk(D, H, V, 4, seed=11).cuda().eval()
+    with torch.no_grad():
+        W = m.qkv.weight                       # zero the v projection, then bias it through x's last channel
+        W[2 * D:].zero_()
+        W[2 * D:, -1] = torch.linspace(-1, 1, D)
+        m.proj.weight.copy_(torch.eye(D))
+        x = torch.randn(2, 197, D, device="cuda")
+        x[..., -1] = 1.0
+        y = m(x)
+        c = torch.linspace(-1, 1, D, device="cuda").view(H, D // H)
+        exp = c * m.v_scale[0, :, 0] + torch.sigmoid(m.chain_value_logit) * c * m.v_scale[V - 1, :, 0]
+    assert max_abs(y.cpu().numpy(), exp.reshape(1, 1, D).expand_as(y).cpu().numpy()) <= 1e-2
