@@ -45,7 +45,7 @@ def build_layer(dtype):
     return m.cuda().to(dtype)
 
 
-def cpu_baseline(sample_b=8, reps=3):
+def cpu_baseline(sample_b=32, reps=5):
     """The numpy oracle (a port of the reference path) timed on this box's host cores."""
     import numpy as np
     from oracle import edgewise as oe

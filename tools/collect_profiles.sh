@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): bench + rocprofv3 kernel-trace stats + PMC passes (each its own run) for round $1
+set -o pipefail
+R=${1:-r01}
+export TMPDIR=/tmp
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/$R
+mkdir -p $OUT
+python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/kt.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq1 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq1.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_sq2.log 2>&1 || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_grbm.log 2>&1 || exit 1
+for p in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_grbm; do python3 tools/pmc_summary.py "$OUT/$p/*/*counter_collection.csv" > $OUT/$p.txt; done
+cp $OUT/kt/*/*kernel_stats.csv $OUT/kernel_stats.csv
+tail -1 $OUT/bench.json | cut -c1-600
