@@ -976,6 +976,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             {
                 const int mp = V - 1 - v;
                 bf16x8 Dl[NT][2];
+                __builtin_amdgcn_sched_barrier(0);   // keep these loads below GEMM 1 (register pressure)
                 slot_ld(S_DL + mp, Dl);
                 if (mp >= 1) {
                     bf16x8 Bf[NT][2];
@@ -995,8 +996,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
             if (v == V - 1) STAMP();
             REFRESH();
-            // ---- softmax backward + direct + mean terms -> dS_v^T (rolled tile loops; dA and dS live as packed tiles)
-            bf16x8 Sp[NT][2];
+            // ---- softmax backward + direct + mean terms -> dS_v^T, streamed per key tile: each dS tile goes straight
+            //      into the LDS image (A operand of dK) and into dQe_v^T += K^T[:, tile] dS^T[tile, :] (4 MFMAs)
+            f32x16 dq[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
             {
                 const float cv = stats[v * NP + qi];
                 bf16x8 qe[KS];
@@ -1015,6 +1019,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 const float drs = dmean[v * NP + qi];
                 bf16x8 qe0[KS];
                 if (v != 0) make_frag(qe0, qrow, sqk2);
+                lds_barrier();                         // every wave is done reading the D images: R takes the dS^T image
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
                     const f32x16 Sv = s_tile(qe, t);
@@ -1051,15 +1056,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     }
                     bf16x8 lo, hi;
                     pack_tile_bf(lo, hi, dS);
-                    pk_set(Sp, t, lo, hi);
+                    store_i_tile(R, t, lo, hi);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const unsigned short *kt = KT + (32 * dt + r) * LDA + 8 * h + 32 * t;
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)&kt[0], lo, dq[dt], 0, 0, 0);
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)&kt[16], hi, dq[dt], 0, 0, 0);
+                    }
                 }
             }
             if (v == V - 1) STAMP();
             REFRESH();
             // ---- dQe_v^T = K^T dS^T ; dq += sqk_v * dQe_v ; dsqk_v = sum_i q * dQe_v
             {
-                f32x16 dq[DT];
-                gemm_small(dq, KT, Sp);
                 float *acc = dqacc + (((size_t)v * NT + w) * DT * 16) * 64 + lane;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
@@ -1098,9 +1107,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
             if (v == V - 1) STAMP();
             REFRESH();
-            // ---- dK += sqk_v * (dS^T Q) through LDS
-            lds_barrier();
-            store_i_packed(R, Sp);
+            // ---- dK += sqk_v * (dS^T Q) through the LDS image written above
             lds_barrier();
             if (tid < DK) {
                 float s = 0.f;
