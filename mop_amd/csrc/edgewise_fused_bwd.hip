@@ -22,7 +22,8 @@ struct BwdWs {
     size_t stride;           // bytes per workgroup
     size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW, oDA, oStamp;
 };
-enum { S_CF = 0, S_CB, S_C0, S_C1, S_C2, S_C3, S_L, S_DP, S_DS, S_DL };   // S_DL .. S_DL+V-1
+enum { S_CF = 0, S_CB, S_C3, S_L, S_DP, S_DIR };   // S_DIR .. S_DIR+V-1 (direct score gradients per view), then S_DL(V) .. +V-1
+__host__ __device__ constexpr int S_DL(int V) { return S_DIR + V; }
 
 template <int NT, int DK>
 struct BwdCfg {
@@ -42,7 +43,7 @@ struct BwdCfg {
         w.oDYT = o; o += a256((size_t)DP * LDA * 2);
         w.oV0s = o; o += a256((size_t)NP * DK * 2);
         w.oVLs = o; o += a256((size_t)NP * DK * 2);
-        w.oSlots = o; o += a256((size_t)(S_DL + V) * NT * SLOT);
+        w.oSlots = o; o += a256((size_t)(S_DL(V) + V) * NT * SLOT);
         w.oStats = o; o += a256((size_t)V * NP * 2 * 4);
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
         w.oAcc = o; o += a256((size_t)2 * V * NT * DT * 16 * 64 * 4);   // per-view dq / dk partials (write-only, summed in P11)
@@ -692,25 +693,49 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int g = 0; g < 16; ++g) dS[g] = (32 * t + tile_row(g, h) < N) ? P[g] * (dP[g] - delta) : 0.f;
         }
-        f32x16 O = zero16();
+        // pass 1: gates -> gA = G_and - nb G_not, g1 = G_or ; lse tile ; per-view direct score gradients
+        //   dS_v(direct) = dSmix * (v == 0 ? 1 - g1 + g1 pi_0 : gA + g1 pi_v),  pi_v = exp(S_v - lse)   -> parked per view
+        f32x16 O = zero16(), lse;
         {
+            f32x16 gA = gate_tile(t, 0), g1;
+            { const f32x16 G2 = gate_tile(t, 2);
+#pragma unroll
+              for (int g = 0; g < 16; ++g) gA[g] = fmaf(-nb, G2[g], gA[g]); }
+            g1 = gate_tile(t, 1);
             bf16x8 qe[KS];
-            for (int v = 1; v < V; ++v) {
+            {
+                const u32x4 *p = slot(S_L);
+                lse = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]) * 0.6931471805599453f;   // L = lse - S0 (parked * log2 e)
+            }
+            for (int v = 0; v < V; ++v) {
                 make_frag(qe, qrow, sqk + v * DK);
                 const f32x16 Sv = s_tile(qe, t);
-                O += Sv;
+                if (v == 0) lse += Sv; else O += Sv;
+                f32x16 dir;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float pi = __expf(Sv[g] - lse[g]);
+                    const float coef = v == 0 ? (1.f - g1[g]) + g1[g] * pi : fmaf(g1[g], pi, gA[g]);
+                    dir[g] = dS[g] * coef;
+                }
+                bf16x8 bl, bh;
+                pack_tile_bf(bl, bh, dir);
+                u32x4 *p = slot(S_DIR + v); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
             }
         }
+        // pass 2: gate gradients.  terms: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
         f32x16 L, Cr;
         {
-            const u32x4 *p = slot(S_L);
-            L = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]) * 0.6931471805599453f;
+            bf16x8 qe[KS];
+            make_frag(qe, qrow, sqk);
+            const f32x16 S0 = s_tile(qe, t);
+            L = lse - S0;
             const u32x4 *pc = slot(S_CF);
             Cr = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
 #pragma unroll
             for (int g = 0; g < 16; ++g) Cr[g] = __logf(Cr[g] + EPSC);
         }
-        f32x16 c0 = dS, c1 = zero16(), dbt = zero16();
+        f32x16 dbt = zero16();
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x16 G = gate_tile(t, g4);
@@ -720,26 +745,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 const float term = g4 == 0 ? O[g] : (g4 == 1 ? L[g] : (g4 == 2 ? -nb * O[g] : Cr[g]));
                 dZ[g] = dS[g] * term * G[g] * (1.f - G[g]);
             }
-            if (g4 == 0) {
-#pragma unroll
-                for (int g = 0; g < 16; ++g) c1[g] = dS[g] * G[g];
-            } else if (g4 == 1) {
-                u32x4 lo, hi; bf16x8 bl, bh;
-                f32x16 c2;
-#pragma unroll
-                for (int g = 0; g < 16; ++g) { c2[g] = dS[g] * G[g]; c0[g] -= c2[g]; }
-                pack_tile_bf(bl, bh, c2);
-                u32x4 *p = slot(S_C2); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
-                pack_tile_bf(bl, bh, c0);
-                p = slot(S_C0); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
-                (void)lo; (void)hi;
-            } else if (g4 == 2) {
-                bf16x8 bl, bh;
-#pragma unroll
-                for (int g = 0; g < 16; ++g) c1[g] -= nb * dS[g] * G[g];
-                pack_tile_bf(bl, bh, c1);
-                u32x4 *p = slot(S_C1); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
-            } else {
+            if (g4 == 3) {
                 bf16x8 bl, bh;
                 f32x16 c3;
 #pragma unroll
@@ -920,17 +926,17 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * t + tile_row(g, h);
-                    d[g] = (j < N && qok) ? (drl + dmean[(2 * V + 3) * NP + j]) / (cb[g] + EPSC) : 0.f;
+                    d[g] = (j < N && qok) ? (drl + dmean[(2 * V + 3) * NP + j]) * __builtin_amdgcn_rcpf(cb[g] + EPSC) : 0.f;
                 }
                 pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
         }
         for (int m = V - 1; m >= 1; --m) {
-            slot_st(S_DL + m, Dp);
+            slot_st(S_DL(V) + m, Dp);
             a_image(R, V - 1 - m, true, true);         // A_av (rows = queries)
             gemm_packed(Dp, R);                        // D'_{m-1}^T = A_av D'_m^T
         }
-        slot_st(S_DL, Dp);
+        slot_st(S_DL(V), Dp);
     }
     STAMP();
     REFRESH();
@@ -952,7 +958,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * t + tile_row(g, h);
-                    d[g] = (j < N && qok) ? (c3[g] + drr + dmean[(2 * V + 1) * NP + j]) / (cf[g] + EPSC) + wv * dyv[g] : 0.f;
+                    d[g] = (j < N && qok) ? (c3[g] + drr + dmean[(2 * V + 1) * NP + j]) * __builtin_amdgcn_rcpf(cf[g] + EPSC) + wv * dyv[g] : 0.f;
                 }
                 pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
@@ -960,31 +966,42 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int v = V - 1; v >= 0; --v) {
             slot_st(S_DP, Dp);                         // park D_v (B operand of the D-chain step below)
             REFRESH();
-            // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index), kept as packed bf16 tiles
+            // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index), kept as packed bf16 tiles; the
+            //      softmax-backward row dot  sum_j A_v dA_v  is taken from the fp32 accumulators of the LAST contribution
             bf16x8 dAp[NT][2];
+            const int mp = V - 1 - v;
             if (v >= 1) {
                 bf16x8 Bf[NT][2];
                 load_rows(Bf, Tg + (size_t)(v - 1) * NP * LDA);          // in flight across the barriers below
                 lds_barrier();
                 store_i_packed(R, Dp);
                 lds_barrier();
-                gemm_acc_packed(dAp, R, Bf, false);
+#pragma unroll
+                for (int to = 0; to < NT; ++to) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x16 acc = gemm_tile(zero16(), R, to, Bf);
+                    pack_tile_bf(dAp[to][0], dAp[to][1], acc);
+                }
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { dAp[t][0] = Dp[t][0]; dAp[t][1] = Dp[t][1]; }
             }
             {
-                const int mp = V - 1 - v;
                 bf16x8 Dl[NT][2];
                 __builtin_amdgcn_sched_barrier(0);   // keep these loads below GEMM 1 (register pressure)
-                slot_ld(S_DL + mp, Dl);
+                slot_ld(S_DL(V) + mp, Dl);
                 if (mp >= 1) {
                     bf16x8 Bf[NT][2];
                     load_rows(Bf, Ug + (size_t)(mp - 1) * NP * LDA);
                     lds_barrier();
                     store_i_packed(R, Dl);
                     lds_barrier();
-                    gemm_acc_packed(dAp, R, Bf, true);
+#pragma unroll
+                    for (int to = 0; to < NT; ++to) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f32x16 acc = gemm_tile(unpack_tile_bf(dAp[to][0], dAp[to][1]), R, to, Bf);
+                        pack_tile_bf(dAp[to][0], dAp[to][1], acc);
+                    }
                 } else {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
@@ -996,54 +1013,34 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
             if (v == V - 1) STAMP();
             REFRESH();
+            // ---- softmax-backward row dot  sum_j A_v dA_v  (rolled pass over key tiles)
+            const float cv = stats[v * NP + qi];
+            bf16x8 qe[KS];
+            make_frag(qe, qrow, sqk2 + v * DK);           // base-2 scores: A = 2^(S' - c)
+            float dot = 0.f;
+#pragma nounroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x16 A = a_tile(qe, t, cv);
+                bf16x8 dl_, dh_;
+                pk_get(dAp, t, dl_, dh_);
+                const f32x16 dA = unpack_tile_bf(dl_, dh_);
+#pragma unroll
+                for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dA[g], dot);
+            }
+            dot += __shfl_xor(dot, 32, 64);
             // ---- softmax backward + direct + mean terms -> dS_v^T, streamed per key tile: each dS tile goes straight
             //      into the LDS image (A operand of dK) and into dQe_v^T += K^T[:, tile] dS^T[tile, :] (4 MFMAs)
             f32x16 dq[DT];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
             {
-                const float cv = stats[v * NP + qi];
-                bf16x8 qe[KS];
-                make_frag(qe, qrow, sqk2 + v * DK);       // base-2 scores: A = 2^(S' - c), pi = 2^(S'_v - S'_0 - L')
-                float dot = 0.f;
-#pragma nounroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x16 A = a_tile(qe, t, cv);
-                    bf16x8 dl_, dh_;
-                    pk_get(dAp, t, dl_, dh_);
-                    const f32x16 dA = unpack_tile_bf(dl_, dh_);
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dA[g], dot);
-                }
-                dot += __shfl_xor(dot, 32, 64);
                 const float drs = dmean[v * NP + qi];
-                bf16x8 qe0[KS];
-                if (v != 0) make_frag(qe0, qrow, sqk2);
                 lds_barrier();                         // every wave is done reading the D images: R takes the dS^T image
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x16 Sv = s_tile(qe, t);
-                    f32x16 pi;
-                    {
-                        const u32x4 *p = slot(S_L);
-                        pi = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);        // L = lse - S0
-                        if (v != 0) {
-                            const f32x16 S0 = s_tile(qe0, t);
-#pragma unroll
-                            for (int g = 0; g < 16; ++g) pi[g] = __builtin_amdgcn_exp2f(Sv[g] - S0[g] - pi[g]);
-                        } else {
-#pragma unroll
-                            for (int g = 0; g < 16; ++g) pi[g] = __builtin_amdgcn_exp2f(-pi[g]);
-                        }
-                    }
-                    {
-                        const u32x4 *p2 = slot(S_C2);
-                        const f32x16 c2 = unpack_tile_bf(as_b8(p2[(2 * t) * 64]), as_b8(p2[(2 * t + 1) * 64]));
-                        const u32x4 *pc = slot(v == 0 ? S_C0 : S_C1);
-                        const f32x16 cd = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
-#pragma unroll
-                        for (int g = 0; g < 16; ++g) pi[g] = fmaf(c2[g], pi[g], cd[g]);
-                    }
+                    const f32x16 A = a_tile(qe, t, cv);
+                    const u32x4 *pd = slot(S_DIR + v);
+                    const f32x16 dir = unpack_tile_bf(as_b8(pd[(2 * t) * 64]), as_b8(pd[(2 * t + 1) * 64]));
                     bf16x8 dl_, dh_;
                     pk_get(dAp, t, dl_, dh_);
                     const f32x16 dA = unpack_tile_bf(dl_, dh_);
@@ -1051,8 +1048,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * t + tile_row(g, h);
-                        const float A = __builtin_amdgcn_exp2f(Sv[g] - cv);
-                        dS[g] = j < N ? A * (dA[g] - dot) + pi[g] + drs + dmean[(V + v) * NP + j] : 0.f;
+                        dS[g] = j < N ? A[g] * (dA[g] - dot) + dir[g] + drs + dmean[(V + v) * NP + j] : 0.f;
                     }
                     bf16x8 lo, hi;
                     pack_tile_bf(lo, hi, dS);
