@@ -108,6 +108,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
     };
     auto make_qe = [&](bf16x8 (&qe)[KS], int v) { make_qe_t(qe, sqk, v); };      // natural scores (mix)
+    // same from raw q fragments already in registers (no global round trip inside the mix tile loop)
+    auto scale_qe = [&](bf16x8 (&qe)[KS], const bf16x8 (&qraw)[KS], int v) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 s0 = *(const float4 *)&sqk[v * DK + 16 * s + 8 * h], s1 = *(const float4 *)&sqk[v * DK + 16 * s + 8 * h + 4];
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qe[s][j] = (short)f2bf(bf2f((unsigned short)qraw[s][j]) * sc[j]);
+        }
+    };
     auto make_qe2 = [&](bf16x8 (&qe)[KS], int v) { make_qe_t(qe, sqk2, v); };    // scores * log2(e) (softmax slabs: exp2, no multiply)
     auto s_tile = [&](const bf16x8 (&qe)[KS], int t) -> f32x16 {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -403,6 +413,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         for (int g = 0; g < 16; ++g) z[g] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z[g]));
         return z;
     };
+    bf16x8 qraw[KS];                      // raw q fragments resident through the mix loop
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(qrow + 16 * s + 8 * h); qraw[s] = v; }
     // runtime loop over key tiles (an unrolled one makes hipcc overlap the tiles' live ranges and
     // spill ~1000 VGPRs); the per-tile packed Cr/Smix registers are selected with a uniform switch.
 #pragma nounroll
@@ -417,14 +430,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         f32x16 S0, O, L;
         {
             bf16x8 qe[KS];
-            make_qe(qe, 0);
+            scale_qe(qe, qraw, 0);
             S0 = s_tile(qe, t);
             f32x16 mx = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, se;
             O = mx;
 #pragma unroll
             for (int g = 0; g < 16; ++g) se[g] = 1.f;
             for (int v = 1; v < V; ++v) {     // online logsumexp over views, relative to S_0
-                make_qe(qe, v);
+                scale_qe(qe, qraw, v);
                 const f32x16 Sv = s_tile(qe, t);
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {

@@ -234,6 +234,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             qe[s] = qv;
         }
     };
+    // Qe_v fragments from raw q fragments already in registers (no global round trip inside tile loops)
+    auto scale_frag = [&](bf16x8 (&qe)[KS], const bf16x8 (&qraw)[KS], const float *scale) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 s0 = *(const float4 *)&scale[16 * s + 8 * h], s1 = *(const float4 *)&scale[16 * s + 8 * h + 4];
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qe[s][j] = (short)f2bf(bf2f((unsigned short)qraw[s][j]) * sc[j]);
+        }
+    };
     auto s_tile = [&](const bf16x8 (&qe)[KS], int t) -> f32x16 {                   // S^T tile [key, query] from K in LDS
         const unsigned short *kbase = Ksm + r * LDK + 8 * h;   // lane base + compile-time offsets
         f32x16 acc = zero16();
@@ -591,6 +601,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             for (int p = 0; p < 8; ++p) crp[k][p] = cw[p];
         }
     };
+    bf16x8 qraw[KS];                     // raw q fragments, resident through the mix phases (P4-P6)
+    make_frag(qraw, qrow, nullptr);
     float mxrow = -INFINITY;
 #pragma nounroll
     for (int t = 0; t < NT; ++t) {
@@ -599,14 +611,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         f32x16 S0, O, L;
         {
             bf16x8 qe[KS];
-            make_frag(qe, qrow, sqk);
+            scale_frag(qe, qraw, sqk);
             S0 = s_tile(qe, t);
             f32x16 mx = zero16(), se;
             O = mx;
 #pragma unroll
             for (int g = 0; g < 16; ++g) se[g] = 1.f;
             for (int v = 1; v < V; ++v) {
-                make_frag(qe, qrow, sqk + v * DK);
+                scale_frag(qe, qraw, sqk + v * DK);
                 const f32x16 Sv = s_tile(qe, t);
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
@@ -708,7 +720,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 lse = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]) * 0.6931471805599453f;   // L = lse - S0 (parked * log2 e)
             }
             for (int v = 0; v < V; ++v) {
-                make_frag(qe, qrow, sqk + v * DK);
+                scale_frag(qe, qraw, sqk + v * DK);
                 const f32x16 Sv = s_tile(qe, t);
                 if (v == 0) lse += Sv; else O += Sv;
                 f32x16 dir;
@@ -727,7 +739,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         f32x16 L, Cr;
         {
             bf16x8 qe[KS];
-            make_frag(qe, qrow, sqk);
+            scale_frag(qe, qraw, sqk);
             const f32x16 S0 = s_tile(qe, t);
             L = lse - S0;
             const u32x4 *pc = slot(S_CF);
@@ -942,6 +954,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ================= P10: -> chain backward with per-view totals =================
     {
+        f32x16 dq_acc[DT], dk_acc[DT];                 // dq^T [d, my query] and dk [key of tile w, d] summed over views
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dq_acc[dt] = zero16(); dk_acc[dt] = zero16(); }
         // dC->^T slab, packed tile by tile
         bf16x8 Dp[NT][2];
         {
@@ -1065,7 +1080,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             REFRESH();
             // ---- dQe_v^T = K^T dS^T ; dq += sqk_v * dQe_v ; dsqk_v = sum_i q * dQe_v
             {
-                float *acc = dqacc + (((size_t)v * NT + w) * DT * 16) * 64 + lane;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     float c[16];
@@ -1081,7 +1095,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         for (int e = 0; e < 4; ++e) {
                             const int g = 4 * g4 + e;
                             const float sc = d0 < DK ? sqk[v * DK + d0 + e] : 0.f;
-                            acc[(size_t)(dt * 16 + g) * 64] = sc * dq[dt][g];
+                            dq_acc[dt][g] = fmaf(sc, dq[dt][g], dq_acc[dt][g]);
                             c[g] = qok ? qv[e] * dq[dt][g] : 0.f;
                         }
                     }
@@ -1113,13 +1127,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             {
                 f32x16 dk[DT];
                 gemm_rows_glob(dk, R, QT);             // (dS^T q)[j in tile w][d]
-                float *acc = dkacc + (((size_t)v * NT + w) * DT * 16) * 64 + lane;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const int d = 32 * dt + r;
                     const float sc = d < DK ? sqk[v * DK + d] : 0.f;
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) acc[(size_t)(dt * 16 + g) * 64] = sc * dk[dt][g];
+                    for (int g = 0; g < 16; ++g) dk_acc[dt][g] = fmaf(sc, dk[dt][g], dk_acc[dt][g]);
                 }
             }
             if (v == V - 1) STAMP();
@@ -1131,45 +1144,34 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 gemm_packed(Dp, R);
             }
         }
-    }
-    STAMP();
-    REFRESH();
-    // ================= P11: write dq, dk (sum of the per-view partials) =================
-    {
-        IOT *dqp = (IOT *)a.dq.ptr + b * a.dq.sb + hh * a.dq.sh + (int64_t)qi * a.dq.sn;
-        const float *acc = dqacc + ((size_t)w * DT * 16) * 64 + lane;
-        const size_t vs = (size_t)NT * DT * 16 * 64;
-        if (qok) {
+        // ================= P11: write dq, dk =================
+        REFRESH();
+        {
+            IOT *dqp = (IOT *)a.dq.ptr + b * a.dq.sb + hh * a.dq.sh + (int64_t)qi * a.dq.sn;
+            if (qok) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int d0 = 32 * dt + 8 * g4 + 4 * h;
-                    if (d0 < DK) {
-                        float o[4] = {0.f, 0.f, 0.f, 0.f};
-                        for (int v = 0; v < V; ++v)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] += acc[v * vs + (size_t)(dt * 16 + 4 * g4 + e) * 64];
-                        store4<IOT>(dqp + d0, o[0], o[1], o[2], o[3]);
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int d0 = 32 * dt + 8 * g4 + 4 * h;
+                        if (d0 < DK) store4<IOT>(dqp + d0, dq_acc[dt][4 * g4], dq_acc[dt][4 * g4 + 1], dq_acc[dt][4 * g4 + 2], dq_acc[dt][4 * g4 + 3]);
                     }
-                }
-        }
-        IOT *dkp = (IOT *)a.dk_.ptr + b * a.dk_.sb + hh * a.dk_.sh;
-        const float *kacc = dkacc + ((size_t)w * DT * 16) * 64 + lane;
+            }
+            IOT *dkp = (IOT *)a.dk_.ptr + b * a.dk_.sb + hh * a.dk_.sh;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int d = 32 * dt + r;
-            if (d < DK) {
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 32 * dt + r;
+                if (d < DK) {
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int j = 32 * w + tile_row(g, h);
-                    float o = 0.f;
-                    for (int v = 0; v < V; ++v) o += kacc[v * vs + (size_t)(dt * 16 + g) * 64];
-                    if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, o);
+                    for (int g = 0; g < 16; ++g) {
+                        const int j = 32 * w + tile_row(g, h);
+                        if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, dk_acc[dt][g]);
+                    }
                 }
             }
         }
     }
+    STAMP();
     __syncthreads();      // LDS / scratch reuse by the next (b,h)
     }   // persistent loop
     STAMP();
