@@ -22,7 +22,7 @@ struct BwdWs {
     size_t stride;           // bytes per workgroup
     size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW, oDA, oStamp;
 };
-enum { S_CF = 0, S_CB, S_C3, S_L, S_DP, S_DIR };   // S_DIR .. S_DIR+V-1 (direct score gradients per view), then S_DL(V) .. +V-1
+enum { S_CF = 0, S_CB, S_C3, S_L, S_DP, S_SM, S_DIR };   // S_DIR .. S_DIR+V-1 (direct score gradients per view), then S_DL(V) .. +V-1
 __host__ __device__ constexpr int S_DL(int V) { return S_DIR + V; }
 
 template <int NT, int DK>
@@ -511,7 +511,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ================= P1/P2: forward chains (recompute) =================
     __syncthreads();                     // P0 global images + LDS complete
-    unsigned int crp[NT][8];
     {
         bf16x8 Xp[NT][2];
         run_chain(Xp, false, Ug);
@@ -521,7 +520,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
         run_chain(Xp, true, Tg);
         slot_st(S_CF, Xp);
-        log_means_packed(Xp, rCr, crp);
+        log_means_packed(Xp, rCr, nullptr);
     }
     __syncthreads();
     if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
@@ -587,27 +586,15 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int g = 0; g < 16; ++g) z[g] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z[g]));
         return z;
     };
-    auto crp_get = [&](unsigned int (&cw)[8], int t) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) if (t == k) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) cw[p] = crp[k][p];
-        }
-    };
-    auto crp_set = [&](int t, const unsigned int (&cw)[8]) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) if (t == k) {
-#pragma unroll
-            for (int p = 0; p < 8; ++p) crp[k][p] = cw[p];
-        }
-    };
     bf16x8 qraw[KS];                     // raw q fragments, resident through the mix phases (P4-P6)
     make_frag(qraw, qrow, nullptr);
-    float mxrow = -INFINITY;
+    bf16x8 dyf[KS];
+    make_frag(dyf, dyrow, nullptr);
+    // online softmax over key tiles of the mixed logits, fused with delta_i = sum_j P dP (dP tile = V0 dy^T):
+    //   running max m, l = sum e, dn = sum e * dP  ->  P = e / l, delta = dn / l.   Smix is parked (fp16) per tile.
+    float om = -1e30f, ol = 0.f, odn = 0.f;
 #pragma nounroll
     for (int t = 0; t < NT; ++t) {
-        unsigned int cw[8];
-        crp_get(cw, t);
         f32x16 S0, O, L;
         {
             bf16x8 qe[KS];
@@ -647,48 +634,50 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         { const f32x16 G = gate_tile(t, 2);
 #pragma unroll
           for (int g = 0; g < 16; ++g) S0[g] = fmaf(-nb * G[g], O[g], S0[g]); }
-        { const f32x16 G = gate_tile(t, 3);
+        {
+            const f32x16 G = gate_tile(t, 3);
+            const u32x4 *pc = slot(S_CF);
+            const f32x16 cf = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
+            float tm = -1e30f;
 #pragma unroll
-          for (int p = 0; p < 8; ++p) {
-              float s0 = fmaf(G[2 * p], h2_lo(cw[p]), S0[2 * p]);
-              float s1 = fmaf(G[2 * p + 1], h2_hi(cw[p]), S0[2 * p + 1]);
-              if (32 * t + tile_row(2 * p, h) >= N) s0 = -INFINITY;
-              if (32 * t + tile_row(2 * p + 1, h) >= N) s1 = -INFINITY;
-              mxrow = fmaxf(mxrow, fmaxf(s0, s1));
-              cw[p] = pack_h2(s0, s1);
-          } }
-        crp_set(t, cw);
+            for (int g = 0; g < 16; ++g) {
+                float sm = fmaf(G[g], __logf(cf[g] + EPSC), S0[g]);
+                if (32 * t + tile_row(g, h) >= N) sm = -1e30f;
+                S0[g] = sm;
+                tm = fmaxf(tm, sm);
+            }
+            u32x4 lo, hi;
+            pack_tile_h(lo, hi, S0);
+            u32x4 *p = slot(S_SM);
+            p[(2 * t) * 64] = lo; p[(2 * t + 1) * 64] = hi;
+            const f32x16 dP = g_tile(V0s, dyf, t);
+            const f32x16 Sq = unpack_tile_h(lo, hi);          // the fp16-rounded logits every later pass sees
+            const float mn = fmaxf(om, tm);
+            float sl = 0.f, sd = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) { const float e = __expf(Sq[g] - mn); sl += e; sd = fmaf(e, dP[g], sd); }
+            const float f = __expf(om - mn);
+            ol = fmaf(ol, f, sl); odn = fmaf(odn, f, sd); om = mn;
+        }
     }
-    mxrow = fmaxf(mxrow, __shfl_xor(mxrow, 32, 64));
-    float lsum = 0.f;
+    float mxrow, invl, delta;
+    {
+        const float m2 = __shfl_xor(om, 32, 64), l2 = __shfl_xor(ol, 32, 64), d2 = __shfl_xor(odn, 32, 64);
+        mxrow = fmaxf(om, m2);
+        const float f1 = __expf(om - mxrow), f2 = __expf(m2 - mxrow);
+        const float lt = ol * f1 + l2 * f2;
+        invl = 1.f / lt;
+        delta = (odn * f1 + d2 * f2) * invl;
+    }
+    auto p_tile = [&](int t) -> f32x16 {      // P tile from the parked Smix
+        const u32x4 *p = slot(S_SM);
+        f32x16 x = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int p = 0; p < 8; ++p) lsum += __expf(h2_lo(crp[t][p]) - mxrow) + __expf(h2_hi(crp[t][p]) - mxrow);
-    lsum += __shfl_xor(lsum, 32, 64);
-    const float invl = 1.f / lsum;
-    auto p_tile = [&](const unsigned int (&cw)[8]) -> f32x16 {      // P tile from packed Smix
-        f32x16 p;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { p[2 * q] = __expf(h2_lo(cw[q]) - mxrow) * invl; p[2 * q + 1] = __expf(h2_hi(cw[q]) - mxrow) * invl; }
-        return p;
+        for (int g = 0; g < 16; ++g) x[g] = __expf(x[g] - mxrow) * invl;
+        return x;
     };
     STAMP();
     REFRESH();
-    // ================= P5: delta_i = sum_j P dP =================
-    bf16x8 dyf[KS];
-    make_frag(dyf, dyrow, nullptr);
-    float delta = 0.f;
-#pragma nounroll
-    for (int t = 0; t < NT; ++t) {
-        unsigned int cw[8];
-        crp_get(cw, t);
-        const f32x16 P = p_tile(cw);
-        const f32x16 dP = g_tile(V0s, dyf, t);
-#pragma unroll
-        for (int g = 0; g < 16; ++g) delta = fmaf(P[g], dP[g], delta);
-    }
-    delta += __shfl_xor(delta, 32, 64);
     STAMP();
     REFRESH();
     // ================= P6: mix backward =================
@@ -696,11 +685,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     unsigned short *tb = tbuf + w * 32 * 40;
 #pragma nounroll
     for (int t = 0; t < NT; ++t) {
-        unsigned int cw[8];
-        crp_get(cw, t);
         f32x16 dS;                                   // dSmix tile
         {
-            const f32x16 P = p_tile(cw);
+            const f32x16 P = p_tile(t);
             const f32x16 dP = g_tile(V0s, dyf, t);
 #pragma unroll
             for (int g = 0; g < 16; ++g) dS[g] = (32 * t + tile_row(g, h) < N) ? P[g] * (dP[g] - delta) : 0.f;
@@ -857,9 +844,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     {
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            unsigned int cw[8];
-            crp_get(cw, t);
-            const f32x16 P = p_tile(cw);
+            const f32x16 P = p_tile(t);
             bf16x8 lo, hi;
             pack_tile_bf(lo, hi, P);
             store_i_tile(R, t, lo, hi);
