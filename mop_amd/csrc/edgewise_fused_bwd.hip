@@ -1035,12 +1035,31 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
             {
                 const float drs = dmean[v * NP + qi];
+                // software prefetch: the parked direct-gradient tile and the K^T fragments of tile t+1 are requested
+                // while tile t is computed (a rolled loop exposes one full L2/HBM round trip per iteration otherwise)
+                const u32x4 *pd = slot(S_DIR + v);
+                const unsigned short *ktb = KT + r * LDA + 8 * h;
+                u32x4 nd0 = pd[0], nd1 = pd[64];
+                bf16x8 nk[DT][2];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA]; nk[dt][1] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 16]; }
                 lds_barrier();                         // every wave is done reading the D images: R takes the dS^T image
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
+                    const u32x4 d0 = nd0, d1 = nd1;
+                    bf16x8 kf[DT][2];
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) { kf[dt][0] = nk[dt][0]; kf[dt][1] = nk[dt][1]; }
+                    if (t + 1 < NT) {
+                        nd0 = pd[(2 * t + 2) * 64]; nd1 = pd[(2 * t + 3) * 64];
+#pragma unroll
+                        for (int dt = 0; dt < DT; ++dt) {
+                            nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * (t + 1)];
+                            nk[dt][1] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * (t + 1) + 16];
+                        }
+                    }
                     const f32x16 A = a_tile(qe, t, cv);
-                    const u32x4 *pd = slot(S_DIR + v);
-                    const f32x16 dir = unpack_tile_bf(as_b8(pd[(2 * t) * 64]), as_b8(pd[(2 * t + 1) * 64]));
+                    const f32x16 dir = unpack_tile_bf(as_b8(d0), as_b8(d1));
                     bf16x8 dl_, dh_;
                     pk_get(dAp, t, dl_, dh_);
                     const f32x16 dA = unpack_tile_bf(dl_, dh_);
@@ -1055,9 +1074,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     store_i_tile(R, t, lo, hi);
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) {
-                        const unsigned short *kt = KT + (32 * dt + r) * LDA + 8 * h + 32 * t;
-                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)&kt[0], lo, dq[dt], 0, 0, 0);
-                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)&kt[16], hi, dq[dt], 0, 0, 0);
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[dt][0], lo, dq[dt], 0, 0, 0);
+                        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[dt][1], hi, dq[dt], 0, 0, 0);
                     }
                 }
             }
