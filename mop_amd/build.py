@@ -33,10 +33,13 @@ def _jobs():
     jobs = [(s, [], s.replace(".hip", ".o")) for s in PLAIN]
     for s in FUSED:
         stem = s.replace(".hip", "")
+        # fused bf16-MFMA kernels: relaxed fp (reassociation, contraction, approximate reciprocals) but inf/nan kept;
+        # the exact-fp32 generic path is built without it
+        fm = ["-ffast-math", "-fno-finite-math-only"]
         jobs.append((s, ["-DMOPK_INST_NT=0", "-DMOPK_INST_DK=0"], f"{stem}_disp.o"))
         for nt in NTS:
             for dk in DKS:
-                jobs.append((s, [f"-DMOPK_INST_NT={nt}", f"-DMOPK_INST_DK={dk}"], f"{stem}_nt{nt}_dk{dk}.o"))
+                jobs.append((s, fm + [f"-DMOPK_INST_NT={nt}", f"-DMOPK_INST_DK={dk}"], f"{stem}_nt{nt}_dk{dk}.o"))
     return jobs
 
 
