@@ -84,6 +84,9 @@ typedef struct MopkEdgewiseArgs {
     int32_t io_dtype;   /* MopkDtype of q,k,v,y,dy,dq,dk,dv        */
     int32_t precision;  /* MopkPrecision                           */
     int32_t path;       /* MopkPath                                */
+    int32_t save_for_backward; /* fused path: 1 = fwd also exports the chain state (prefix products, softmax constants,
+                                * log-means) into `saved` and _bwd reads it instead of recomputing; must have the same
+                                * value in the fwd call, the bwd call and both *_bytes() queries.  0 = small `saved`. */
     float beta_not;     /* :361, used at :546 */
 
     MopkView5 q, k;          /* per-view (sv!=0) or shared (sv==0) queries / keys  :461-470 */

@@ -28,7 +28,7 @@ class EdgewiseArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("dk", C.c_int32),
         ("V", C.c_int32), ("r", C.c_int32), ("io_dtype", C.c_int32), ("precision", C.c_int32),
-        ("path", C.c_int32), ("beta_not", C.c_float),
+        ("path", C.c_int32), ("save_for_backward", C.c_int32), ("beta_not", C.c_float),
         ("q", View5), ("k", View5), ("v0", View4), ("vL", View4),
         ("sqk", _fp), ("vs0", _fp), ("vsL", _fp), ("Wr", _fp), ("br", _fp), ("Wc", _fp), ("bc", _fp),
         ("chain_logit", _fp),

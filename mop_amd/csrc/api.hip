@@ -8,6 +8,7 @@ int ew_generic_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_generic_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
+size_t ew_fused_saved_bytes(const MopkEdgewiseArgs *a);
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a);
 size_t ew_fused_bwd_ws_bytes(const MopkEdgewiseArgs *a);
 int ew_fused_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
@@ -64,7 +65,7 @@ const char *mopk_edgewise_dominant_kernel(const MopkEdgewiseArgs *a, int backwar
 
 size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a) {
     if (!a || a->B <= 0 || a->H <= 0 || a->N <= 0 || a->dk <= 0 || a->V < 2 || a->r < 1) return 0;
-    if (a->path == MOPK_PATH_FUSED) return (size_t)a->B * a->H * a->N * a->dk * sizeof(float) + 256;  // w * y_chain
+    if (a->path == MOPK_PATH_FUSED) return ew_fused_fwd_supported(a) ? ew_fused_saved_bytes(a) : 0;
     return ew_generic_saved_bytes(a);
 }
 size_t mopk_edgewise_workspace_bytes(const MopkEdgewiseArgs *a) {

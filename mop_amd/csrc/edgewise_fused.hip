@@ -22,7 +22,7 @@
 
 namespace mopk {
 
-template <int NT, int DK, typename IOT>
+template <int NT, int DK, typename IOT, bool SAVE>
 __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs a) {
     using Cfg = FusedCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = Cfg::LDK, KS = Cfg::KS, DT = Cfg::DT, DP = Cfg::DP;
@@ -93,6 +93,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     __syncthreads();
     }
 
+    const FusedSavedLayout SL = fused_saved_layout<NT, DK>(N, V, SAVE);
+    unsigned char *svb = (unsigned char *)a.saved + (size_t)blockIdx.x * SL.stride;    // this (b,h)'s record
     // ---------------- helpers ----------------
     const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
     auto make_qe_t = [&](bf16x8 (&qe)[KS], const float *tab, int v) {   // Qe_v fragments; q re-read from L2 (keeps 16 VGPRs free)
@@ -234,6 +236,25 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, c); pack_tile(Xp[t][0], Xp[t][1], A); }
         }
         for (int m = 1; m < V; ++m) {
+            if (SAVE) {                       // export the prefix product T_{m-1}^T (AT image) for the backward's dA GEMMs
+                __syncthreads();              // previous step's readers of AT are done
+#pragma nounroll
+                for (int t = 0; t < NT; ++t) {
+                    bf16x8 lo = Xp[0][0], hi = Xp[0][1];
+                    switch (t) {
+#define MOPK_GP(K_) case K_: if (K_ < NT) { lo = Xp[K_ < NT ? K_ : 0][0]; hi = Xp[K_ < NT ? K_ : 0][1]; } break;
+                        MOPK_GP(1) MOPK_GP(2) MOPK_GP(3) MOPK_GP(4) MOPK_GP(5) MOPK_GP(6)
+#undef MOPK_GP
+                        default: break;
+                    }
+                    store_AT_tile(t, lo, hi);
+                }
+                __syncthreads();
+                typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+                u4 *out = (u4 *)(svb + (forward ? SL.oT : SL.oU) + (size_t)(m - 1) * NP * LDA * 2);
+                const u4 *src = (const u4 *)AT;
+                for (int c8 = tid; c8 < N * LDA / 8; c8 += NT * 64) out[c8] = src[c8];      // rows >= N are never read back
+            }
             {
                 const int v = forward ? m : V - 1 - m;
                 bf16x8 qe[KS];
@@ -266,7 +287,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     // ---------------- chain <- : only its log-means survive           :513-515, :521
     {
         float rs = 0.f;
-        run_chain(false, [&](int to, f32x16 &acc) { log_tile(acc, to, rs); });
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        u4 *cbp = (u4 *)(svb + SL.oCB + (size_t)w * NT * 8 * 64 * 4) + lane;       // packed C<- slab of this wave
+        run_chain(false, [&](int to, f32x16 &acc) {
+            if (SAVE) { bf16x8 lo, hi; pack_tile(lo, hi, acc); cbp[(2 * to) * 64] = __builtin_bit_cast(u4, lo); cbp[(2 * to + 1) * 64] = __builtin_bit_cast(u4, hi); }
+            log_tile(acc, to, rs);
+        });
         rs += __shfl_xor(rs, 32, 64);
         if (h == 0) rCl[qi] = rs * invN;
     }
@@ -276,10 +302,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     // ---------------- chain -> : C-> kept as packed bf16 (for y_chain) and log C-> as packed fp16 (for the mix)
     unsigned int crp[NT][8];              // Cr (later Smix) as packed fp16
     IOT *yp = (IOT *)a.y.ptr + b * a.y.sb + hh * a.y.sh + (int64_t)qi * a.y.sn;
-    float *ych = (float *)a.saved + (size_t)blockIdx.x * N * DK;   // saved: w * y_chain (BH,N,dk) fp32
+    float *ych = (float *)(svb + SL.oYch);                         // saved: w * y_chain (N,dk) fp32
     {
         bf16x8 Xc[NT][2];
         run_chain(true, [&](int to, f32x16 &acc) { pack_tile(Xc[to][0], Xc[to][1], acc); });
+        if (SAVE) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+            u4 *cfp = (u4 *)(svb + SL.oCF + (size_t)w * NT * 8 * 64 * 4) + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { cfp[(2 * t) * 64] = __builtin_bit_cast(u4, Xc[t][0]); cfp[(2 * t + 1) * 64] = __builtin_bit_cast(u4, Xc[t][1]); }
+        }
         // log C-> from the bf16-rounded product (the same rounding the backward sees): means + packed fp16 copy
         float rs = 0.f;
 #pragma unroll
@@ -311,7 +343,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 }
             }
             if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NT * 64) { VT0[DK * LDA + c] = 0; VTL[DK * LDA + c] = 0; }
-            if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
+            if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; c *= invN; cCr[tid] = c;
+                            if (SAVE) ((float *)(svb + SL.oMeans))[2 * NP + tid] = c; }
+            if (SAVE) {   // softmax constants of every view (still in `cst`, about to be overwritten by rS) and the log-means
+                float *gc = (float *)(svb + SL.oCst), *gm = (float *)(svb + SL.oMeans);
+                for (int c = tid; c < V * NP; c += NT * 64) gc[c] = cst[c];
+                if (tid < NP) { gm[tid] = rCr[tid]; gm[NP + tid] = rCl[tid]; gm[3 * NP + tid] = cCl[tid]; }
+                __syncthreads();          // cst fully copied before rS/cS overwrite it
+            }
             // row / col means of S_v are linear in q, k:  rS_v[i] = Qe_v[i,:].kbar ; cS_v[j] = k[j,:].(sqk_v*qbar)
             // (written over the softmax constants `cst`, which the chains no longer need)
             {
@@ -532,25 +571,28 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #define MOPK_CAT_(a, b, c, d) a##b##c##d
 #define MOPK_CAT(a, b, c, d) MOPK_CAT_(a, b, c, d)
 #if MOPK_INST_NT != 0
+size_t MOPK_CAT(ew_fused_saved_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a) {
+    return fused_saved_layout<MOPK_INST_NT, MOPK_INST_DK>(a->N, a->V, a->save_for_backward != 0).stride * (size_t)a->B * a->H + 256;
+}
 int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st) {
     constexpr int NT = MOPK_INST_NT, DK = MOPK_INST_DK;
     const int lds = FusedCfg<NT, DK>::lds_bytes(a->V);
     if (lds > 160 * 1024) return MOPK_ERR_UNSUPPORTED;
     const dim3 grid(a->B * a->H), block(NT * 64);
-    if (a->io_dtype == MOPK_BF16) {
-        auto kfn = ew_fused_fwd_kernel<NT, DK, unsigned short>;
-        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a);
-    } else {
-        auto kfn = ew_fused_fwd_kernel<NT, DK, float>;
-        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a);
-    }
+#define MOPK_LAUNCH(IOT_, SAVE_) do {                                                                             \
+        auto kfn = ew_fused_fwd_kernel<NT, DK, IOT_, SAVE_>;                                                      \
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a);                                                        \
+    } while (0)
+    if (a->io_dtype == MOPK_BF16) { if (a->save_for_backward) MOPK_LAUNCH(unsigned short, true); else MOPK_LAUNCH(unsigned short, false); }
+    else { if (a->save_for_backward) MOPK_LAUNCH(float, true); else MOPK_LAUNCH(float, false); }
+#undef MOPK_LAUNCH
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
 }
 #else
-#define MOPK_DECL(NT_, DK_) int ew_fused_fwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st);
+#define MOPK_DECL(NT_, DK_) int ew_fused_fwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st); \
+                            size_t ew_fused_saved_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a);
 MOPK_DECL(1, 16) MOPK_DECL(1, 32) MOPK_DECL(1, 64) MOPK_DECL(2, 16) MOPK_DECL(2, 32) MOPK_DECL(2, 64)
 MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
 #undef MOPK_DECL
@@ -583,6 +625,11 @@ int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
     return 1;
 }
 
+size_t ew_fused_saved_bytes(const MopkEdgewiseArgs *a) {
+#define MOPK_DKS(NT_) switch (a->dk) { case 16: return ew_fused_saved_nt##NT_##_dk16(a); case 32: return ew_fused_saved_nt##NT_##_dk32(a); default: return ew_fused_saved_nt##NT_##_dk64(a); }
+    switch (pick_nt(a->N)) { case 1: MOPK_DKS(1) case 2: MOPK_DKS(2) case 4: MOPK_DKS(4) case 7: MOPK_DKS(7) default: return 0; }
+#undef MOPK_DKS
+}
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     if (!ew_fused_fwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
 #define MOPK_DK(NT_)                                                         \

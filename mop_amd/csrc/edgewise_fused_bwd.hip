@@ -32,12 +32,12 @@ struct BwdCfg {
     static constexpr size_t MAT = (size_t)NP * LDA * 2;
     static constexpr size_t SLOT = (size_t)NT * 8 * 64 * 4;                // one packed slab of one wave
     static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
-    static BwdWs carve(void *base, int V) {
+    static BwdWs carve(void *base, int V, bool saved) {      // saved: prefix products live in the forward's `saved` buffer
         BwdWs w{};
         size_t o = 0;
         w.base = (unsigned char *)base;
-        w.oT = o; o += a256((size_t)(V - 1) * MAT);
-        w.oU = o; o += a256((size_t)(V - 1) * MAT);
+        w.oT = o; o += saved ? 0 : a256((size_t)(V - 1) * MAT);
+        w.oU = o; o += saved ? 0 : a256((size_t)(V - 1) * MAT);
         w.oKT = o; o += a256((size_t)DP * LDA * 2);
         w.oQT = o; o += a256((size_t)DP * LDA * 2);
         w.oDYT = o; o += a256((size_t)DP * LDA * 2);
@@ -87,7 +87,7 @@ __device__ __forceinline__ f32x16 unpack_tile_h(u32x4 lo, u32x4 hi) {
 }
 __device__ __forceinline__ f32x16 zero16() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
 
-template <int NT, int DK, typename IOT>
+template <int NT, int DK, typename IOT, bool SAVED>
 __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W) {
     using Cfg = BwdCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = DK + 8, KS = DK / 16, DT = Cfg::DT, DP = Cfg::DP;
@@ -122,14 +122,22 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     const int C = 2 * V + 2;
 
     unsigned char *ws = W.base + (size_t)blockIdx.x * W.stride;
-    unsigned short *Tg = (unsigned short *)(ws + W.oT), *Ug = (unsigned short *)(ws + W.oU);
+    const FusedSavedLayout SL = fused_saved_layout<NT, DK>(a.N, a.V, SAVED);
+    const unsigned char *svb = (const unsigned char *)a.saved;          // record of the current (b,h) (set per iteration)
+    // SAVED: the forward exported the prefix products, final products, softmax constants and log-means -> no recompute
+    const unsigned short *Tg = (const unsigned short *)(ws + W.oT), *Ug = (const unsigned short *)(ws + W.oU);
     unsigned short *KT = (unsigned short *)(ws + W.oKT), *QT = (unsigned short *)(ws + W.oQT), *DYT = (unsigned short *)(ws + W.oDYT);
     unsigned short *V0s = (unsigned short *)(ws + W.oV0s), *VLs = (unsigned short *)(ws + W.oVLs);
     float *stats = (float *)(ws + W.oStats);                          // [V][NP] softmax constants c_v[i] (log2 of the row sum of 2^S')
+    const float *cstats = stats;                                      // read side (SAVED: the forward's copy)
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
     float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)a.V * NT * DT * 16 * 64;   // [V][NT][DT*16][64]
     float *dwp = (float *)(ws + W.oDW);
-    auto slot = [&](int s) -> u32x4 * { return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane; };
+    auto slot = [&](int s) -> u32x4 * {
+        if (SAVED && (s == S_CF || s == S_CB))       // read-only in this mode
+            return (u32x4 *)(svb + (s == S_CF ? SL.oCF : SL.oCB) + (size_t)w * Cfg::SLOT) + lane;
+        return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane;
+    };
     // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
 
 #ifdef MOPK_STAMPS
@@ -143,7 +151,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     for (int bh = blockIdx.x; bh < a.B * H; bh += gridDim.x) {
     const int b = bh / H, hh = bh % H;
     const bool first_pass = bh == (int)blockIdx.x;
-    const float *ych = (const float *)a.saved + (size_t)bh * N * DK;   // w * y_chain from the fused forward
+    svb = (const unsigned char *)a.saved + (size_t)bh * SL.stride;
+    const float *ych = (const float *)(svb + SL.oYch);                 // w * y_chain from the fused forward
+    if (SAVED) {
+        Tg = (const unsigned short *)(svb + SL.oT); Ug = (const unsigned short *)(svb + SL.oU);
+        cstats = (const float *)(svb + SL.oCst);
+    }
     STAMP();
     const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
     const IOT *dyrow = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)qi * a.dy.sn;
@@ -355,11 +368,17 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
     };
     auto load_rows = [&](bf16x8 (&Bf)[NT][2], const unsigned short *Bm) {      // this lane's row of a global AT image (14 x 16 B)
-        const unsigned short *brow = Bm + (size_t)qi * LDA + 8 * h;
+        const unsigned short *brow = Bm + (size_t)(SAVED && !qok ? 0 : qi) * LDA + 8 * h;   // SAVED images hold rows < N only
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int s = 0; s < 2; ++s) Bf[t][s] = *(const bf16x8 *)&brow[32 * t + 16 * s];
+        if (SAVED && !qok) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) Bf[t][s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
     };
     // Pk[to] (+)= Am rows . Bf   with the running sum kept as packed bf16 tiles
     auto gemm_acc_packed = [&](bf16x8 (&Pk)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
@@ -461,7 +480,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     auto a_image = [&](unsigned short *dst, int v, bool form_ii, bool have_stats) {
         bf16x8 qe[KS];
         make_frag(qe, qrow, sqk2 + v * DK);
-        const float c = have_stats ? stats[v * NP + qi] : row_const(qe, v);
+        const float c = have_stats ? cstats[v * NP + qi] : row_const(qe, v);
         lds_barrier();                    // previous readers of dst are done
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
@@ -473,7 +492,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     };
     // forward chain recompute on packed state; every prefix product T_m (m = 0..V-2) is staged in R (AT format)
     // and copied to Pg[m]; returns the final product in Xp
-    auto run_chain = [&](bf16x8 (&Xp)[NT][2], bool forward, unsigned short *Pg) {
+    auto run_chain = [&](bf16x8 (&Xp)[NT][2], bool forward, unsigned short *Pg) {   // !SAVED only
         {
             const int v = forward ? 0 : V - 1;
             bf16x8 qe[KS];
@@ -511,19 +530,22 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ================= P1/P2: forward chains (recompute) =================
     __syncthreads();                     // P0 global images + LDS complete
-    {
+    if (SAVED) {
+        const float *gm = (const float *)(svb + SL.oMeans);
+        if (tid < NP) { rCr[tid] = gm[tid]; rCl[tid] = gm[NP + tid]; cCr[tid] = gm[2 * NP + tid]; cCl[tid] = gm[3 * NP + tid]; }
+    } else {
         bf16x8 Xp[NT][2];
-        run_chain(Xp, false, Ug);
+        run_chain(Xp, false, (unsigned short *)Ug);
         slot_st(S_CB, Xp);
         log_means_packed(Xp, rCl, nullptr);
         __syncthreads();
         if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
-        run_chain(Xp, true, Tg);
+        run_chain(Xp, true, (unsigned short *)Tg);
         slot_st(S_CF, Xp);
         log_means_packed(Xp, rCr, nullptr);
+        __syncthreads();
+        if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
     }
-    __syncthreads();
-    if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
     __syncthreads();
     STAMP();
     REFRESH();
@@ -1014,7 +1036,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             if (v == V - 1) STAMP();
             REFRESH();
             // ---- softmax-backward row dot  sum_j A_v dA_v  (rolled pass over key tiles)
-            const float cv = stats[v * NP + qi];
+            const float cv = cstats[v * NP + qi];
             bf16x8 qe[KS];
             make_frag(qe, qrow, sqk2 + v * DK);           // base-2 scores: A = 2^(S' - c)
             float dot = 0.f;
@@ -1186,7 +1208,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #if MOPK_INST_NT != 0
 static int bwd_grid(const MopkEdgewiseArgs *a) { const int bh = a->B * a->H; return bh < 256 ? bh : 256; }   // one persistent WG per CU
 size_t MOPK_CAT(ew_fused_bwd_ws_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a) {
-    return BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::carve(nullptr, a->V).stride * (size_t)bwd_grid(a) + 256;
+    return BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::carve(nullptr, a->V, a->save_for_backward != 0).stride * (size_t)bwd_grid(a) + 256;
 }
 void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st);
 int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st) {
@@ -1194,18 +1216,18 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     using Cfg = BwdCfg<NT, DK>;
     const int lds = Cfg::lds_bytes(a->V);
     if (lds > 160 * 1024 || 2 * a->V + 2 > 18) return MOPK_ERR_UNSUPPORTED;
-    const BwdWs W = Cfg::carve(a->workspace, a->V);
+    const BwdWs W = Cfg::carve(a->workspace, a->V, a->save_for_backward != 0);
     const int nwg = bwd_grid(a);
     const dim3 grid(nwg), block(NT * 64);
-    if (a->io_dtype == MOPK_BF16) {
-        auto kfn = ew_fused_bwd_kernel<NT, DK, unsigned short>;
-        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);
-    } else {
-        auto kfn = ew_fused_bwd_kernel<NT, DK, float>;
-        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH;
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);
-    }
+#define MOPK_LAUNCH(IOT_, SAVED_) do {                                                                            \
+        auto kfn = ew_fused_bwd_kernel<NT, DK, IOT_, SAVED_>;                                                     \
+        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);                                                     \
+    } while (0)
+    // save_for_backward must match the forward call that filled `saved`
+    if (a->io_dtype == MOPK_BF16) { if (a->save_for_backward) MOPK_LAUNCH(unsigned short, true); else MOPK_LAUNCH(unsigned short, false); }
+    else { if (a->save_for_backward) MOPK_LAUNCH(float, true); else MOPK_LAUNCH(float, false); }
+#undef MOPK_LAUNCH
     MOPK_CHECK_LAUNCH();
     ew_fused_dw_reduce(a, W, nwg, st);
     MOPK_CHECK_LAUNCH();

@@ -67,6 +67,32 @@ __device__ __forceinline__ void pack_slab(bf16x8 (&Xp)[NT][2], const f32x16 (&X)
 }
 
 
+// ---- layout of the fused path's `saved` buffer, one record per (b,h).  Inference forward writes only `ych`
+// (w * y_chain, fp32); the training forward additionally exports what the backward would otherwise recompute:
+// the prefix products T_m / U_m as AT images, the final products C-> / C<- as packed per-wave slabs, the per-view
+// softmax constants and the four log-mean vectors.
+struct FusedSavedLayout {
+    size_t oYch, oT, oU, oCF, oCB, oCst, oMeans, stride;
+};
+template <int NT, int DK>
+__host__ __device__ inline FusedSavedLayout fused_saved_layout(int N, int V, bool full) {
+    constexpr size_t NP = NT * 32, LDA = NP + 8, MAT = NP * LDA * 2, WSLOT = (size_t)NT * 8 * 64 * 4;
+    auto a256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    FusedSavedLayout L{};
+    size_t o = 0;
+    L.oYch = o; o += a256((size_t)N * DK * 4);
+    if (full) {
+        L.oT = o; o += a256((size_t)(V - 1) * MAT);
+        L.oU = o; o += a256((size_t)(V - 1) * MAT);
+        L.oCF = o; o += a256(NT * WSLOT);
+        L.oCB = o; o += a256(NT * WSLOT);
+        L.oCst = o; o += a256((size_t)V * NP * 4);
+        L.oMeans = o; o += a256((size_t)4 * NP * 4);
+    }
+    L.stride = o;
+    return L;
+}
+
 // ---- select / update one 32x32 tile (16 regs) or 8 packed dwords of a register array with a UNIFORM runtime
 // index: keeps the array in VGPRs while letting the tile loop stay rolled (an unrolled loop makes hipcc
 // overlap the tiles' live ranges and spill).
