@@ -252,8 +252,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 __syncthreads();
                 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
                 u4 *out = (u4 *)(svb + (forward ? SL.oT : SL.oU) + (size_t)(m - 1) * NP * LDA * 2);
-                const u4 *src = (const u4 *)AT;
-                for (int c8 = tid; c8 < N * LDA / 8; c8 += NT * 64) out[c8] = src[c8];      // rows >= N are never read back
+                // "row slab" order: [wave w'][chunk q = 2t+s][lane] = 16 B at AT[32w' + r'][32t + 16s + 8h'], i.e. exactly
+                // the B-operand fragments wave w' of the backward loads -> one coalesced 1 KiB access per fragment
+                for (int c8 = tid; c8 < NT * 2 * NT * 64; c8 += NT * 64) {
+                    const int L = c8 & 63, q = (c8 >> 6) % (2 * NT), ws_ = (c8 >> 6) / (2 * NT);
+                    out[c8] = *(const u4 *)&AT[(32 * ws_ + (L & 31)) * LDA + 16 * q + 8 * (L >> 5)];
+                }
             }
             {
                 const int v = forward ? m : V - 1 - m;

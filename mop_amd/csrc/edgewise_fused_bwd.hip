@@ -54,7 +54,9 @@ struct BwdCfg {
         return w;
     }
     // LDS: R region | Ksm | floats
-    static constexpr int R_BYTES = imax(NP * LDA * 2, 4 * NP * BTS * 2 + 2 * 32 * LDA * 2 + NT * 32 * 40 * 2);
+    static constexpr int GATE_BYTES = 4 * NP * BTS * 2 + 2 * 32 * LDA * 2 + NT * 32 * 40 * 2;   // bT | bmat | amat | tbuf
+    static constexpr int WSM_FLOATS = 2 * 16 * 19;                                                // gate-head weights + bias, row | col side
+    static constexpr int R_BYTES = imax(imax(NP * LDA * 2, 3 * DP * LDA * 2), GATE_BYTES + WSM_FLOATS * 4);
     static constexpr int K_BYTES = F::K_BYTES;
     static __host__ __device__ constexpr int small_floats(int V) {
         // sqk[8][DK] qbar kbar vs0 vsL | rCr rCl cCr cCl | colpart[NT][NP] | rS cS [V][NP] (later: dmean[2V+4][NP]) | misc
@@ -98,6 +100,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     unsigned short *bmat = bT + 4 * NP * BTS;                         // [32][LDA] rows rho: b_hi (0-15) / b_lo (16-31), k-permuted cols
     unsigned short *amat = bmat + 32 * LDA;                           // [32][LDA] rows rho: a_hi / a_lo, natural cols
     unsigned short *tbuf = amat + 32 * LDA;                           // [NT][32][40] per-wave 32x32 transpose buffer
+    float *Wsm = (float *)(smem + Cfg::GATE_BYTES);                    // [2][16][19] gate-head weights (+bias at [18]) staged per (b,h) for P3..P7
     float *dav = (float *)R;                                          // [16][NP]  (after the mix-backward loop)
     float *dbv = dav + 16 * NP;                                       // [16][NP]
     unsigned short *Ksm = (unsigned short *)(smem + Cfg::R_BYTES);    // [NP][LDK]
@@ -185,19 +188,29 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             *(bf16x8 *)&Ksm[j * LDK + dc * 8] = kv;
             const int col = (j & ~15) + kperm16(j & 15);
             bf16x8 s0, sL;
+            float sc0[8], scL[8];
+            *(float4 *)&sc0[0] = *(const float4 *)&a.vs0[hh * DK + dc * 8]; *(float4 *)&sc0[4] = *(const float4 *)&a.vs0[hh * DK + dc * 8 + 4];
+            *(float4 *)&scL[0] = *(const float4 *)&a.vsL[hh * DK + dc * 8]; *(float4 *)&scL[4] = *(const float4 *)&a.vsL[hh * DK + dc * 8 + 4];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int d = dc * 8 + e;
-                KT[d * LDA + col] = (unsigned short)kv[e];
-                QT[d * LDA + col] = (unsigned short)qv[e];
-                DYT[d * LDA + col] = (unsigned short)dv[e];
-                s0[e] = (short)f2bf(bf2f((unsigned short)x0[e]) * a.vs0[hh * DK + d]);
-                sL[e] = (short)f2bf(bf2f((unsigned short)xL[e]) * a.vsL[hh * DK + d]);
+                // the three transposed images are assembled in LDS (R is free here) and exported with 16-byte stores
+                R[d * LDA + col] = (unsigned short)kv[e];
+                R[(DP + d) * LDA + col] = (unsigned short)qv[e];
+                R[(2 * DP + d) * LDA + col] = (unsigned short)dv[e];
+                s0[e] = (short)f2bf(bf2f((unsigned short)x0[e]) * sc0[e]);
+                sL[e] = (short)f2bf(bf2f((unsigned short)xL[e]) * scL[e]);
             }
             *(bf16x8 *)&V0s[j * DK + dc * 8] = s0;
             *(bf16x8 *)&VLs[j * DK + dc * 8] = sL;
         }
-        if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NTH) { KT[DK * LDA + c] = 0; QT[DK * LDA + c] = 0; DYT[DK * LDA + c] = 0; }
+        if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NTH) { R[DK * LDA + c] = 0; R[(DP + DK) * LDA + c] = 0; R[(2 * DP + DK) * LDA + c] = 0; }
+        __syncthreads();
+        for (int c = tid; c < DP * LDA / 8; c += NTH) {
+            ((u32x4 *)KT)[c] = ((const u32x4 *)R)[c];
+            ((u32x4 *)QT)[c] = ((const u32x4 *)(R + DP * LDA))[c];
+            ((u32x4 *)DYT)[c] = ((const u32x4 *)(R + 2 * DP * LDA))[c];
+        }
     }
     {   // per-wave partial of qbar
         bf16x8 qf[KS];
@@ -367,18 +380,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             default: break;
         }
     };
-    auto load_rows = [&](bf16x8 (&Bf)[NT][2], const unsigned short *Bm) {      // this lane's row of a global AT image (14 x 16 B)
-        const unsigned short *brow = Bm + (size_t)(SAVED && !qok ? 0 : qi) * LDA + 8 * h;   // SAVED images hold rows < N only
+    auto load_rows = [&](bf16x8 (&Bf)[NT][2], const unsigned short *Bm) {      // this lane's row of an exported image ("row slab" order:
+        const u32x4 *p = (const u32x4 *)Bm + (size_t)w * 2 * NT * 64 + lane;  //  [wave][2t+s][lane] -> coalesced 1 KiB per fragment)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) Bf[t][s] = *(const bf16x8 *)&brow[32 * t + 16 * s];
-        if (SAVED && !qok) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) Bf[t][s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
+            for (int s = 0; s < 2; ++s) Bf[t][s] = as_b8(p[(2 * t + s) * 64]);
     };
     // Pk[to] (+)= Am rows . Bf   with the running sum kept as packed bf16 tiles
     auto gemm_acc_packed = [&](bf16x8 (&Pk)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
@@ -471,10 +478,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
     };
     // copy the AT image staged in R to a global image with coalesced 16-byte accesses (all threads)
-    auto export_R = [&](unsigned short *dst) {
-        const u32x4 *src = (const u32x4 *)R;
+    auto export_R = [&](unsigned short *dst) {                 // AT image in R -> global "row slab" order (see load_rows)
         u32x4 *out = (u32x4 *)dst;
-        for (int c = tid; c < NP * LDA / 8; c += NTH) out[c] = src[c];
+        for (int c = tid; c < NT * 2 * NT * 64; c += NTH) {
+            const int L = c & 63, q = (c >> 6) % (2 * NT), ws_ = (c >> 6) / (2 * NT);
+            out[c] = *(const u32x4 *)&R[(32 * ws_ + (L & 31)) * LDA + 16 * q + 8 * (L >> 5)];
+        }
     };
     // image of A_v (form ii) or A_v^T (form i) streamed tile by tile into dst (LDS)
     auto a_image = [&](unsigned short *dst, int v, bool form_ii, bool have_stats) {
@@ -550,40 +559,41 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     STAMP();
     REFRESH();
     // ================= P3: gate vectors =================
-    if (tid < NP) {
-        const int j = tid;
+    // gate-head weights -> LDS (row side [16][19], col side [16][19]; slot 18 = bias); R's tail is free from here to P7
+    for (int c = tid; c < 2 * 4 * RK * (C + 1); c += NTH) {
+        const int side = c / (4 * RK * (C + 1)), rem = c % (4 * RK * (C + 1)), o = rem / (C + 1), cc = rem % (C + 1);
+        const float *Wg = side ? a.Wc : a.Wr, *bg = side ? a.bc : a.br;
+        Wsm[(side * 16 + o) * 19 + (cc < C ? cc : 18)] = cc < C ? Wg[o * C + cc] : bg[o];
+    }
+    __syncthreads();
+    for (int p = tid; p < 4 * NP; p += NTH) {                  // b side: one (key j, gate g) pair per thread-iteration
+        const int j = p % NP, g = p / NP;
         const int col = (j & ~15) + kperm16(j & 15);
-        for (int g = 0; g < 4; ++g) {
-            unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
-            if (j < N)
-                for (int k = 0; k < RK; ++k) {
-                    const int o = g * RK + k;
-                    float s = a.bc[o];
-                    for (int c = 0; c < C; ++c) {
-                        const float f = c < V ? cS[c * NP + j] : (c < 2 * V ? rS[(c - V) * NP + j] : (c == 2 * V ? cCr[j] : cCl[j]));
-                        s = fmaf(a.Wc[o * C + c], f, s);
-                    }
-                    hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
-                }
-            unsigned short *row = bT + (g * NP + j) * BTS;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0;
-                bmat[(4 * g + k) * LDA + col] = hi[k];
-                bmat[(16 + 4 * g + k) * LDA + col] = lo[k];
+        unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+        if (j < N)
+            for (int k = 0; k < RK; ++k) {
+                const float *Wo = Wsm + (16 + g * RK + k) * 19;
+                float s = Wo[18];
+                for (int c = 0; c < V; ++c) s = fmaf(Wo[c], cS[c * NP + j], fmaf(Wo[V + c], rS[c * NP + j], s));
+                s = fmaf(Wo[2 * V], cCr[j], fmaf(Wo[2 * V + 1], cCl[j], s));
+                hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
             }
+        unsigned short *row = bT + (g * NP + j) * BTS;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0;
+            bmat[(4 * g + k) * LDA + col] = hi[k];
+            bmat[(16 + 4 * g + k) * LDA + col] = lo[k];
         }
     }
     bf16x8 af4[4];
     for (int g = 0; g < 4; ++g) {
         float av[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < RK; ++k) {
-            const int o = g * RK + k;
-            float s = a.br[o];
-            for (int c = 0; c < C; ++c) {
-                const float f = c < V ? rS[c * NP + qi] : (c < 2 * V ? cS[(c - V) * NP + qi] : (c == 2 * V ? rCr[qi] : rCl[qi]));
-                s = fmaf(a.Wr[o * C + c], f, s);
-            }
+            const float *Wo = Wsm + (g * RK + k) * 19;
+            float s = Wo[18];
+            for (int c = 0; c < V; ++c) s = fmaf(Wo[c], rS[c * NP + qi], fmaf(Wo[V + c], cS[c * NP + qi], s));
+            s = fmaf(Wo[2 * V], rCr[qi], fmaf(Wo[2 * V + 1], rCl[qi], s));
             av[k] = s;
         }
 #pragma unroll
@@ -828,35 +838,39 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             const int o = rem / (C + 1), c = rem % (C + 1);
             const int rho = 4 * (o / RK) + (o % RK);
             const float *g = (side ? dbv : dav) + rho * NP;
-            float s = 0.f;
-            for (int n = 0; n < N; ++n) {
-                float f = 1.f;
-                if (c < C) {
-                    if (side == 0) f = c < V ? rS[c * NP + n] : (c < 2 * V ? cS[(c - V) * NP + n] : (c == 2 * V ? rCr[n] : rCl[n]));
-                    else f = c < V ? cS[c * NP + n] : (c < 2 * V ? rS[(c - V) * NP + n] : (c == 2 * V ? cCr[n] : cCl[n]));
-                }
-                s = fmaf(g[n], f, s);
+            // feature row of this (side, channel): row side = [rS | cS | rCr rCl], col side = [cS | rS | cCr cCl]
+            const float *f = nullptr;
+            if (c < V) f = (side ? cS : rS) + c * NP;
+            else if (c < 2 * V) f = (side ? rS : cS) + (c - V) * NP;
+            else if (c == 2 * V) f = side ? cCr : rCr;
+            else if (c == 2 * V + 1) f = side ? cCl : rCl;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int n = 0;
+            if (f) {
+                for (; n + 4 <= N; n += 4) { s0 = fmaf(g[n], f[n], s0); s1 = fmaf(g[n + 1], f[n + 1], s1); s2 = fmaf(g[n + 2], f[n + 2], s2); s3 = fmaf(g[n + 3], f[n + 3], s3); }
+                for (; n < N; ++n) s0 = fmaf(g[n], f[n], s0);
+            } else {
+                for (; n + 4 <= N; n += 4) { s0 += g[n]; s1 += g[n + 1]; s2 += g[n + 2]; s3 += g[n + 3]; }
+                for (; n < N; ++n) s0 += g[n];
             }
+            const float s = (s0 + s1) + (s2 + s3);
             dwp[idx] = first_pass ? s : dwp[idx] + s;
         }
         __syncthreads();
-        if (tid < NP) {
-            const int n = tid;
-            float drow[18], dcol[18];
-            for (int c = 0; c < C; ++c) { drow[c] = 0.f; dcol[c] = 0.f; }
+        // dmean rows: [0,V) drS_v ; [V,2V) dcS_v ; 2V drCr ; 2V+1 dcCr ; 2V+2 drCl ; 2V+3 dcCl   (pre-divided by N)
+        // row m gathers the row-side channel cr and/or the col-side channel cc of the head's input gradient
+        for (int item = tid; item < (2 * V + 4) * NP; item += NTH) {
+            const int m = item / NP, n = item % NP;
+            const int cr = m < 2 * V ? m : (m == 2 * V ? 2 * V : (m == 2 * V + 2 ? 2 * V + 1 : -1));
+            const int cc = m < V ? V + m : (m < 2 * V ? m - V : (m == 2 * V + 1 ? 2 * V : (m == 2 * V + 3 ? 2 * V + 1 : -1)));
+            float sr = 0.f, sc = 0.f;
             if (n < N)
                 for (int o = 0; o < 4 * RK; ++o) {
                     const int rho = 4 * (o / RK) + (o % RK);
-                    const float va = dav[rho * NP + n], vb = dbv[rho * NP + n];
-                    for (int c = 0; c < C; ++c) { drow[c] = fmaf(a.Wr[o * C + c], va, drow[c]); dcol[c] = fmaf(a.Wc[o * C + c], vb, dcol[c]); }
+                    sr = fmaf(Wsm[o * 19 + (cr >= 0 ? cr : 0)], dav[rho * NP + n], sr);
+                    sc = fmaf(Wsm[(16 + o) * 19 + (cc >= 0 ? cc : 0)], dbv[rho * NP + n], sc);
                 }
-            // dmean rows: [0,V) drS_v ; [V,2V) dcS_v ; 2V drCr ; 2V+1 dcCr ; 2V+2 drCl ; 2V+3 dcCl   (pre-divided by N)
-            for (int v = 0; v < V; ++v) {
-                dmean[v * NP + n] = (drow[v] + dcol[V + v]) * invN;
-                dmean[(V + v) * NP + n] = (drow[V + v] + dcol[v]) * invN;
-            }
-            dmean[(2 * V) * NP + n] = drow[2 * V] * invN; dmean[(2 * V + 1) * NP + n] = dcol[2 * V] * invN;
-            dmean[(2 * V + 2) * NP + n] = drow[2 * V + 1] * invN; dmean[(2 * V + 3) * NP + n] = dcol[2 * V + 1] * invN;
+            dmean[item] = ((cr >= 0 ? sr : 0.f) + (cc >= 0 ? sc : 0.f)) * invN;
         }
         __syncthreads();
     }

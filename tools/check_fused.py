@@ -10,6 +10,7 @@ from mop_amd.nn import EdgewiseMSA
 from conftest import golden_names, load_golden
 from gpu_util import module_from_golden, run_fwd_bwd, rel_err, max_abs
 
+ops.set_save_chain_state(os.environ.get("MOPK_SAVE", "1") != "0")
 names = sys.argv[1:] or [n for n in golden_names("ew_") if "unshared" not in n]
 for name in names:
     d, params, gref, meta = load_golden(name)

@@ -16,7 +16,7 @@ ws = ops.LAST_PATH["_bwd_ws"]
 import ctypes as C
 from mop_amd import _lib as L
 a = L.EdgewiseArgs(); a.B, a.H, a.N, a.dk, a.V, a.r = B, 6, 197, 64, 5, 4; a.path = L.PATH_FUSED; a.precision = L.PREC_BF16
-a.io_dtype = L.MOPK_BF16
+a.io_dtype = L.MOPK_BF16; a.save_for_backward = 1
 tot = L.lib().mopk_edgewise_workspace_bytes(C.byref(a))
 stride = (tot - 256) // min(B * 6, 256)
 raw = ws[stride - 512: stride].cpu().numpy().tobytes()
@@ -26,5 +26,5 @@ names = ["P0 stage", "P1/2 fwd chains", "P3 gates", "P4 mix", "P5 delta", "P6 mi
 vals = [s for s in st if s]
 tot_c = vals[-1] - vals[0]
 for i in range(len(vals) - 1):
-    print(f"{names[i] if i < len(names) else i:22s} {vals[i+1]-vals[i]:10d} cyc  {100.0*(vals[i+1]-vals[i])/tot_c:5.1f}%")
+    print(f"{(names[i] if i < len(names) else str(i)):22s} {vals[i+1]-vals[i]:10d} cyc  {100.0*(vals[i+1]-vals[i])/tot_c:5.1f}%")
 print("total", tot_c)
