@@ -150,6 +150,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #else
 #define STAMP() do { } while (0)
 #endif
+#ifdef MOPK_STAMPS2
+#define STAMP2() STAMP()
+#else
+#define STAMP2() do { } while (0)
+#endif
     // persistent workgroup: scratch is indexed by blockIdx (stays hot in L2 / Infinity Cache), (b,h) pairs are strided
     for (int bh = blockIdx.x; bh < a.B * H; bh += gridDim.x) {
     const int b = bh / H, hh = bh % H;
@@ -161,21 +166,23 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         cstats = (const float *)(svb + SL.oCst);
     }
     STAMP();
+    REFRESH();                           // per (b,h): nothing lane-derived may be hoisted out of the persistent loop (it would be spilled)
     const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
     const IOT *dyrow = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)qi * a.dy.sn;
 
     // ================= P0: stage operands =================
     {
+        const int tl = 64 * w + lane;      // == tid, but derived from the refreshed lane id
         const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh;
         const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
         const IOT *dp = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh;
         const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
         const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
-        for (int c = tid; c < V * DK; c += NTH) { const float t = a.sqk[((c / DK) * H + hh) * DK + (c % DK)]; sqk[c] = t; sqk2[c] = t * 1.4426950408889634f; }
-        for (int c = tid; c < DK; c += NTH) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
+        for (int c = tl; c < V * DK; c += NTH) { const float t = a.sqk[((c / DK) * H + hh) * DK + (c % DK)]; sqk[c] = t; sqk2[c] = t * 1.4426950408889634f; }
+        for (int c = tl; c < DK; c += NTH) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
         if (tid == 0) misc[0] = 1.f / (1.f + __expf(-*a.chain_logit));
         constexpr int CH = DK / 8;
-        for (int c = tid; c < NP * CH; c += NTH) {
+        for (int c = tl; c < NP * CH; c += NTH) {
             const int j = c / CH, dc = c % CH;
             bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, qv = kv, dv = kv, x0 = kv, xL = kv;
             if (j < N) {
@@ -204,9 +211,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             *(bf16x8 *)&V0s[j * DK + dc * 8] = s0;
             *(bf16x8 *)&VLs[j * DK + dc * 8] = sL;
         }
-        if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NTH) { R[DK * LDA + c] = 0; R[(DP + DK) * LDA + c] = 0; R[(2 * DP + DK) * LDA + c] = 0; }
+        if (DK < DP) for (int c = tl; c < (DP - DK) * LDA; c += NTH) { R[DK * LDA + c] = 0; R[(DP + DK) * LDA + c] = 0; R[(2 * DP + DK) * LDA + c] = 0; }
         __syncthreads();
-        for (int c = tid; c < DP * LDA / 8; c += NTH) {
+        for (int c = tl; c < DP * LDA / 8; c += NTH) {
             ((u32x4 *)KT)[c] = ((const u32x4 *)R)[c];
             ((u32x4 *)QT)[c] = ((const u32x4 *)(R + DP * LDA))[c];
             ((u32x4 *)DYT)[c] = ((const u32x4 *)(R + 2 * DP * LDA))[c];
