@@ -6,7 +6,6 @@ export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/kt.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1 || exit 1
@@ -15,4 +14,29 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INS
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_grbm.log 2>&1 || exit 1
 for p in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_grbm; do python3 tools/pmc_summary.py "$OUT/$p/*/*counter_collection.csv" > $OUT/$p.txt; done
 cp $OUT/kt/*/*kernel_stats.csv $OUT/kernel_stats.csv
+python3 - "$OUT" <<'PY'
+import json, re, sys
+out = sys.argv[1]
+def grab(path):
+    res, cur = {}, None
+    for line in open(path):
+        m = re.match(r"\s+(\w+)\s+n=\s*\d+ mean=([\d.e+]+)", line)
+        if m and cur:
+            res.setdefault(cur, {})[m.group(1)] = float(m.group(2))
+        elif "mopk" in line:
+            m2 = re.search(r"(ew_fused_\w+_kernel)", line)
+            cur = m2.group(1) if m2 else None
+    return res
+f, w = grab(out + "/pmc_fetch.txt"), grab(out + "/pmc_write.txt")
+note = ("memory-side (fabric) traffic per launch from separate rocprofv3 --pmc passes at B=256; FETCH_SIZE doubled per "
+        "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads); includes Infinity-Cache hits")
+res = {}
+for k in f:
+    fk, wk = f[k].get("FETCH_SIZE", 0.0), w.get(k, {}).get("WRITE_SIZE", 0.0)
+    res[k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024, "note": note}
+json.dump(res, open(out + "/hbm_traffic.json", "w"), indent=1)
+PY
+# bench last: its roofline.traffic field reads the PMC-derived file produced above
+cp $OUT/hbm_traffic.json $ROOT/profiles/${R}_hbm_traffic.json
+python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 tail -1 $OUT/bench.json | cut -c1-600
