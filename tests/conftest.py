@@ -24,5 +24,5 @@ def load_golden(name):
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     params = {k[6:]: v for k, v in d.items() if k.startswith("param:")}
     grads = {k[5:]: v for k, v in d.items() if k.startswith("grad:")}
-    meta = {k[5:]: v.item() for k, v in d.items() if k.startswith("meta:")}
+    meta = {k[5:]: (v.item() if v.ndim == 0 else v) for k, v in d.items() if k.startswith("meta:")}
     return d, params, grads, meta

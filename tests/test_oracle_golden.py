@@ -32,6 +32,25 @@ def test_edgewise(name, dtype):
     _check(out, dx, grads, d, gref)
 
 
+def ewx_oracle_kwargs(meta):
+    """lens-bank arguments of oracle.edgewise.module_fwd from a fixture's meta."""
+    return dict(lens_dilations=tuple(int(v) for v in meta["lens_dilations"]) if meta["use_lens_bank"] else None,
+                lens_qk=(tuple(int(v) for v in meta["lens_qk_dilations"]), bool(meta["lens_qk_causal"]))
+                if meta["use_lens_bank_qk"] else None)
+
+
+@pytest.mark.parametrize("name", golden_names("ewx_"))
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_edgewise_variants(name, dtype):
+    """dense head (+k3), S lens bank, Q/K lens bank against the reference's outputs and autograd gradients."""
+    d, params, gref, meta = load_golden(name)
+    p = {k: v.astype(dtype) for k, v in params.items()}
+    out, cache = edgewise.module_fwd(d["x"].astype(dtype), p, meta["heads"], meta["n_views"], bool(meta["share_qkv"]),
+                                     meta["beta_not"], **ewx_oracle_kwargs(meta))
+    dx, grads = edgewise.module_bwd(d["w"].astype(dtype), cache)
+    _check(out, dx, grads, d, gref)
+
+
 @pytest.mark.parametrize("name", golden_names("mh_"))
 def test_multihop(name):
     d, params, gref, meta = load_golden(name)

@@ -41,6 +41,8 @@ def _perturb(mod: torch.nn.Module, seed: int):
                 p.mul_(3.0)
             elif "row_proj.bias" in name or "col_proj.bias" in name:
                 p.add_(0.3 * torch.randn(p.shape, generator=g))
+            elif name.endswith("conv2.bias"):                     # dense head: bias -5 leaves every gate (and its gradient) ~0
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
             elif name.endswith("mixture"):
                 p.fill_(0.3)
             elif name.endswith("quartet_scale"):
@@ -95,6 +97,41 @@ def edgewise_cases():
         x = torch.randn(B, N, dim)
         meta = dict(kind="edgewise", dim=dim, heads=heads, beta_not=kw.get("beta_not", 0.5),
                     n_views=kw["n_views"], share_qkv=kw["share_qkv"], gate_rank=kw["gate_rank"])
+        extra = {"meta:" + k: np.asarray(v) for k, v in meta.items()}
+        _save(name, _run(mod, x, extra=extra))
+
+
+def edgewise_variant_cases():
+    """dense gate head (+use_k3), S lens bank, Q/K lens bank  (attention_variants.py:250-272, :392-442, :472-533)."""
+    cases = [
+        # name, dim, heads, B, N, kwargs
+        ("ewx_tiny_dense_v2", 64, 4, 2, 8, dict(n_views=2, share_qkv=True, gate_mode="dense", gate_init="and")),
+        ("ewx_tiny_dense_k3_v3", 64, 4, 2, 8, dict(n_views=3, share_qkv=True, gate_mode="dense", use_k3=True)),
+        ("ewx_odd_dense_k3_unshared", 32, 2, 1, 6, dict(n_views=2, share_qkv=False, gate_mode="dense", use_k3=True, gate_init="xor")),
+        ("ewx_mid_dense_k3_v4", 96, 3, 2, 33, dict(n_views=4, share_qkv=True, gate_mode="dense", use_k3=True, beta_not=0.7)),
+        ("ewx_tiny_lowrank_lens", 64, 4, 2, 8, dict(n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2, gate_init="mix5",
+                                                   use_lens_bank=True, lens_dilations=(1, 2))),
+        ("ewx_tiny_lowrank_qklens_causal", 64, 4, 2, 8, dict(n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2,
+                                                            use_lens_bank_qk=True, lens_qk_dilations=(1, 2, 3), lens_qk_causal=True)),
+        ("ewx_tiny_lowrank_lens_qklens", 64, 4, 2, 8, dict(n_views=4, share_qkv=True, gate_mode="lowrank", gate_rank=2, gate_init="mix5",
+                                                          use_lens_bank=True, lens_dilations=(1, 2), use_lens_bank_qk=True,
+                                                          lens_qk_dilations=(2, 3), lens_qk_causal=True)),
+        ("ewx_mid_dense_k3_lens_qk", 96, 3, 2, 33, dict(n_views=3, share_qkv=True, gate_mode="dense", use_k3=True,
+                                                       use_lens_bank=True, lens_dilations=(1, 3), use_lens_bank_qk=True,
+                                                       lens_qk_dilations=(1, 2), lens_qk_causal=False)),
+    ]
+    for i, (name, dim, heads, B, N, kw) in enumerate(cases):
+        torch.manual_seed(500 + i)
+        mod = EdgewiseMSA(dim, heads, **kw).eval()
+        _perturb(mod, 500 + i)
+        x = torch.randn(B, N, dim)
+        meta = dict(kind="edgewise", dim=dim, heads=heads, beta_not=kw.get("beta_not", 0.5), n_views=kw["n_views"],
+                    share_qkv=kw["share_qkv"], gate_rank=kw.get("gate_rank", 4), gate_mode=kw["gate_mode"],
+                    use_k3=kw.get("use_k3", False), use_lens_bank=kw.get("use_lens_bank", False),
+                    lens_dilations=np.asarray(kw.get("lens_dilations", ()), dtype=np.int64),
+                    use_lens_bank_qk=kw.get("use_lens_bank_qk", False),
+                    lens_qk_dilations=np.asarray(kw.get("lens_qk_dilations", ()), dtype=np.int64),
+                    lens_qk_causal=kw.get("lens_qk_causal", False))
         extra = {"meta:" + k: np.asarray(v) for k, v in meta.items()}
         _save(name, _run(mod, x, extra=extra))
 
@@ -168,7 +205,6 @@ def sdpa_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    edgewise_cases()
-    multihop_cases()
-    quartet_cases()
-    sdpa_cases()
+    groups = dict(ew=edgewise_cases, ewx=edgewise_variant_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
+    for name in (sys.argv[1:] or list(groups)):               # e.g. `gen_golden.py ewx` regenerates one group only
+        groups[name]()
