@@ -65,7 +65,7 @@ typedef struct MopkView5 {
 } MopkView5;
 
 /* --------------------------------------------------------------------------
- * EdgewiseMSA attention core, low-rank gate head.
+ * EdgewiseMSA attention core (low-rank gate head; dense head / lens banks through MopkEdgewiseExt).
  * Replaces reference mop/models/attention_variants.py:
  *   EdgewiseMSA.forward :500-562 (scores, per-view softmax, chain products,
  *   log features, gate head :319-331, score-space mix, re-normalise, value
@@ -77,6 +77,27 @@ typedef struct MopkView5 {
  *   sqk_v = q_scale_v * k_scale_v / sqrt(dk).
  * For share_qkv=False pass per-view q/k (sv != 0) and sqk = 1/sqrt(dk).
  * -------------------------------------------------------------------------- */
+/* Optional gate-head / feature variants (generic path only; NULL ext = low-rank head, no lens bank).
+ *   dense head  : reference EdgewiseGateHead dense branch :250-272, :312-318 (Conv2d 1x1 C->16, GELU(tanh),
+ *                 [use_k3: GELU again, Conv2d 3x3 16->16 pad 1], Conv2d 1x1 16->4, sigmoid)
+ *   S lens bank : depthwise dilated 3x3 convolutions of the score planes appended to the feature stack :425-442, :523-533
+ * Feature channel order (C = 2V + 2 + n_lens*V): S_0..S_{V-1}, S_0^T..S_{V-1}^T, Cr, Cl, lens[l*V+v]   :522-533
+ * With the low-rank head and a lens bank, Wr/Wc (and dWr/dWc) are (4r, C) with this C. */
+#define MOPK_MAX_LENS 4
+#define MOPK_DENSE_HIDDEN 16
+typedef struct MopkEdgewiseExt {
+    int32_t gate_mode;          /* 0 = low-rank (row_proj/col_proj), 1 = dense                     :243 */
+    int32_t use_k3;             /* dense only                                                       :253 */
+    int32_t n_lens;             /* number of lens dilations L (0 = no lens bank), <= MOPK_MAX_LENS */
+    int32_t lens_dil[MOPK_MAX_LENS]; /* dilation == padding of each 3x3 depthwise conv             :430-436 */
+    const float *lens_w;        /* (L,V,3,3) = lens_bank.{l}.weight[:,0]                            */
+    const float *W1, *b1;       /* edge_head.conv1 (16,C) / (16)                                    :251 */
+    const float *W3, *b3;       /* edge_head.mid3 (16,16,3,3) / (16), use_k3 only                   :254 */
+    const float *W2, *b2;       /* edge_head.conv2 (4,16) / (4)                                     :255 */
+    /* backward outputs, fully reduced on device (any may be NULL when the matching input is unused) */
+    float *dlens_w, *dW1, *db1, *dW3, *db3, *dW2, *db2;
+} MopkEdgewiseExt;
+
 typedef struct MopkEdgewiseArgs {
     int32_t B, H, N, dk;
     int32_t V;          /* number of score views (>= 2)            :362 */
@@ -110,12 +131,16 @@ typedef struct MopkEdgewiseArgs {
     float *dvs0_part, *dvsL_part; /* out: (B,H,dk) */
     float *dWr, *dbr, *dWc, *dbc; /* out: (4r,2V+2),(4r),(4r,2V+2),(4r) -- fully reduced */
     float *dlogit_part;      /* out: (B,H) */
+
+    const MopkEdgewiseExt *ext; /* host pointer; NULL = low-rank head without lens bank (the only form the fused path takes) */
 } MopkEdgewiseArgs;
 
 size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a);
 size_t mopk_edgewise_workspace_bytes(const MopkEdgewiseArgs *a);
-int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream);
+int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream);   /* requires ext == NULL or ext->gate_mode == 0 */
 int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream);
+int mopk_edgewise_fwd(const MopkEdgewiseArgs *a, void *stream);           /* any head / lens variant (ext) */
+int mopk_edgewise_bwd(const MopkEdgewiseArgs *a, void *stream);
 
 /* --------------------------------------------------------------------------
  * MultiHopMSA (dual-path, scalar gates) attention core.

@@ -24,6 +24,19 @@ class View5(C.Structure):
 _fp = C.c_void_p  # device pointers travel as void*
 
 
+MAX_LENS = 4          # MOPK_MAX_LENS
+DENSE_HIDDEN = 16     # MOPK_DENSE_HIDDEN
+
+
+class EdgewiseExt(C.Structure):
+    """MopkEdgewiseExt: dense gate head / S lens bank (generic path)."""
+    _fields_ = [
+        ("gate_mode", C.c_int32), ("use_k3", C.c_int32), ("n_lens", C.c_int32), ("lens_dil", C.c_int32 * MAX_LENS),
+        ("lens_w", _fp), ("W1", _fp), ("b1", _fp), ("W3", _fp), ("b3", _fp), ("W2", _fp), ("b2", _fp),
+        ("dlens_w", _fp), ("dW1", _fp), ("db1", _fp), ("dW3", _fp), ("db3", _fp), ("dW2", _fp), ("db2", _fp),
+    ]
+
+
 class EdgewiseArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("dk", C.c_int32),
@@ -36,6 +49,7 @@ class EdgewiseArgs(C.Structure):
         ("dy", View4), ("dq", View5), ("dk_", View5), ("dv0", View4), ("dvL", View4),
         ("dsqk_part", _fp), ("dvs0_part", _fp), ("dvsL_part", _fp),
         ("dWr", _fp), ("dbr", _fp), ("dWc", _fp), ("dbc", _fp), ("dlogit_part", _fp),
+        ("ext", C.POINTER(EdgewiseExt)),
     ]
 
 
@@ -89,6 +103,8 @@ SYMBOLS = {
     "mopk_edgewise_workspace_bytes": (C.c_size_t, [C.POINTER(EdgewiseArgs)]),
     "mopk_edgewise_lowrank_fwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
     "mopk_edgewise_lowrank_bwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
+    "mopk_edgewise_fwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
+    "mopk_edgewise_bwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
     "mopk_dualpath_saved_bytes": (C.c_size_t, [C.POINTER(DualPathArgs)]),
     "mopk_dualpath_workspace_bytes": (C.c_size_t, [C.POINTER(DualPathArgs)]),
     "mopk_dualpath_fwd": (C.c_int, [C.POINTER(DualPathArgs), C.c_void_p]),

@@ -24,13 +24,25 @@ static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
     if (a->B <= 0 || a->H <= 0 || a->N <= 0 || a->dk <= 0 || a->V < 2 || a->r < 1) return MOPK_ERR_BAD_SHAPE;
     if (a->io_dtype != MOPK_F32 && a->io_dtype != MOPK_BF16) return MOPK_ERR_BAD_ARG;
     if (a->precision != MOPK_PREC_FP32 && a->precision != MOPK_PREC_BF16) return MOPK_ERR_BAD_ARG;
-    if (!a->q.ptr || !a->k.ptr || !a->v0.ptr || !a->vL.ptr || !a->sqk || !a->vs0 || !a->vsL || !a->Wr || !a->br ||
-        !a->Wc || !a->bc || !a->chain_logit || !a->saved || !a->workspace)
+    const MopkEdgewiseExt *x = a->ext;
+    const bool dense = x && x->gate_mode == 1;
+    if (x) {
+        if ((x->gate_mode != 0 && x->gate_mode != 1) || x->n_lens < 0 || x->n_lens > MOPK_MAX_LENS) return MOPK_ERR_BAD_ARG;
+        for (int l = 0; l < x->n_lens; ++l) if (x->lens_dil[l] < 1) return MOPK_ERR_BAD_ARG;
+        if (x->n_lens > 0 && (!x->lens_w || (bwd && !x->dlens_w))) return MOPK_ERR_BAD_ARG;
+        if (dense && (!x->W1 || !x->b1 || !x->W2 || !x->b2 || (x->use_k3 && (!x->W3 || !x->b3)))) return MOPK_ERR_BAD_ARG;
+        if (dense && bwd && (!x->dW1 || !x->db1 || !x->dW2 || !x->db2 || (x->use_k3 && (!x->dW3 || !x->db3)))) return MOPK_ERR_BAD_ARG;
+        if ((dense || x->n_lens > 0) && a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;   // generic path only
+    }
+    if (!a->q.ptr || !a->k.ptr || !a->v0.ptr || !a->vL.ptr || !a->sqk || !a->vs0 || !a->vsL || !a->chain_logit || !a->saved ||
+        !a->workspace)
         return MOPK_ERR_BAD_ARG;
+    if (!dense && (!a->Wr || !a->br || !a->Wc || !a->bc)) return MOPK_ERR_BAD_ARG;
     if (!bwd && !a->y.ptr) return MOPK_ERR_BAD_ARG;
     if (bwd && (!a->dy.ptr || !a->dq.ptr || !a->dk_.ptr || !a->dv0.ptr || !a->dvL.ptr || !a->dsqk_part ||
-                !a->dvs0_part || !a->dvsL_part || !a->dWr || !a->dbr || !a->dWc || !a->dbc || !a->dlogit_part))
+                !a->dvs0_part || !a->dvsL_part || !a->dlogit_part))
         return MOPK_ERR_BAD_ARG;
+    if (bwd && !dense && (!a->dWr || !a->dbr || !a->dWc || !a->dbc)) return MOPK_ERR_BAD_ARG;
     if ((a->q.sv == 0) != (a->k.sv == 0)) return MOPK_ERR_BAD_ARG;
     if (bwd && ((a->dq.sv == 0) != (a->q.sv == 0) || (a->dk_.sv == 0) != (a->k.sv == 0))) return MOPK_ERR_BAD_ARG;
     return MOPK_OK;
@@ -73,17 +85,25 @@ size_t mopk_edgewise_workspace_bytes(const MopkEdgewiseArgs *a) {
     if (a->path == MOPK_PATH_FUSED) return ew_fused_fwd_supported(a) ? ew_fused_bwd_ws_bytes(a) : 0;   // backward scratch (forward needs none)
     return ew_generic_workspace_bytes(a);
 }
-int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {
+int mopk_edgewise_fwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, false);
     if (rc) return rc;
     if (a->path == MOPK_PATH_FUSED) return ew_fused_fwd(a, (hipStream_t)stream);
     return ew_generic_fwd(a, (hipStream_t)stream);
 }
-int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream) {
+int mopk_edgewise_bwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, true);
     if (rc) return rc;
     if (a->path == MOPK_PATH_FUSED) return ew_fused_bwd(a, (hipStream_t)stream);
     return ew_generic_bwd(a, (hipStream_t)stream);
+}
+int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {
+    if (a && a->ext && a->ext->gate_mode != 0) return MOPK_ERR_BAD_ARG;
+    return mopk_edgewise_fwd(a, stream);
+}
+int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream) {
+    if (a && a->ext && a->ext->gate_mode != 0) return MOPK_ERR_BAD_ARG;
+    return mopk_edgewise_bwd(a, stream);
 }
 
 // ---- sibling cores (generic multi-kernel paths, attn_generic.hip) ----

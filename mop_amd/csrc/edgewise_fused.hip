@@ -615,6 +615,7 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
     if (a->precision != MOPK_PREC_BF16) return 0;             // fused kernels are the bf16-MFMA path
+    if (a->ext && (a->ext->gate_mode != 0 || a->ext->n_lens > 0)) return 0;   // dense head / lens bank: generic path
     if (a->q.sv != 0 || a->k.sv != 0) return 0;               // share_qkv only (per-view K restaging not built)
     if (pick_nt(a->N) == 0) return 0;
     if (a->dk != 16 && a->dk != 32 && a->dk != 64) return 0;

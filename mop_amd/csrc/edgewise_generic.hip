@@ -1,4 +1,4 @@
-// EdgewiseMSA low-rank core -- generic multi-kernel path (any N / dk / V<=8 / r<=8).
+// EdgewiseMSA core -- generic multi-kernel path (any N / dk / V<=8 / r<=8; low-rank or dense gate head, S lens bank).
 //
 // Every N x N map lives in fp32 in the caller's `saved` / `workspace` buffers and
 // every contraction is a bgemm (bgemm.h), so this path is HBM-bound by design: it
@@ -14,21 +14,42 @@
 
 namespace mopk {
 
-constexpr int MAXV = 8, MAXR = 8;
+constexpr int MAXV = 8, MAXR = 8, MAXL = MOPK_MAX_LENS, HID = MOPK_DENSE_HIDDEN;
+constexpr int MAXC = 2 * MAXV + 2 + MAXL * MAXV;          // feature channels: S, S^T, Cr, Cl, lens[l*V+v]   :522-533
 constexpr float EPS_CHAIN = 1e-6f;  // attention_variants.py:516
 
 struct EwDims {
     int B, H, N, dk, V, r, Vk, C, LD;
     int64_t BH;
+    int dense, k3, L;                // gate-head / lens-bank variant (MopkEdgewiseExt)
+    int dil[MAXL];
 };
 static EwDims ew_dims(const MopkEdgewiseArgs *a) {
-    EwDims d;
+    EwDims d{};
     d.B = a->B; d.H = a->H; d.N = a->N; d.dk = a->dk; d.V = a->V; d.r = a->r;
     d.Vk = a->k.sv == 0 ? 1 : a->V;
-    d.C = 2 * a->V + 2;
     d.LD = (int)round_up(a->N, 4);
     d.BH = (int64_t)a->B * a->H;
+    if (a->ext) {
+        d.dense = a->ext->gate_mode == 1; d.k3 = d.dense && a->ext->use_k3; d.L = a->ext->n_lens;
+        for (int l = 0; l < MAXL; ++l) d.dil[l] = l < d.L ? a->ext->lens_dil[l] : 0;
+    }
+    d.C = 2 * a->V + 2 + d.L * a->V;
     return d;
+}
+// device copy of the variant parameters (the ext struct itself is host memory)
+struct EwExt {
+    const float *lens_w, *W1, *b1, *W3, *b3, *W2, *b2;
+    float *dlens_w, *dW1, *db1, *dW3, *db3, *dW2, *db2;
+};
+static EwExt ew_ext(const MopkEdgewiseArgs *a) {
+    EwExt e{};
+    if (a->ext) {
+        const MopkEdgewiseExt &x = *a->ext;
+        e.lens_w = x.lens_w; e.W1 = x.W1; e.b1 = x.b1; e.W3 = x.W3; e.b3 = x.b3; e.W2 = x.W2; e.b2 = x.b2;
+        e.dlens_w = x.dlens_w; e.dW1 = x.dW1; e.db1 = x.db1; e.dW3 = x.dW3; e.db3 = x.db3; e.dW2 = x.dW2; e.db2 = x.db2;
+    }
+    return e;
 }
 
 struct EwSaved {
@@ -42,6 +63,8 @@ struct EwSaved {
     float *P;                     // (BH,N,LD)
     float *ychain;                // (BH,N,dk)
     float *wsig;                  // 1
+    float *Lz, *rL, *cL;          // lens bank: (L*V,BH,N,LD) planes and their row / col means (L*V,BH,N)
+    float *G, *X1, *H2, *X3;      // dense head: gates (4,BH,N,LD); conv1 pre-activation, conv3 input / output (HID,BH,N,LD)
 };
 static EwSaved ew_carve_saved(void *p, const EwDims &d, size_t *total) {
     Carver c(p);
@@ -56,6 +79,9 @@ static EwSaved ew_carve_saved(void *p, const EwDims &d, size_t *total) {
     s.rCr = c.take<float>(n1); s.cCr = c.take<float>(n1); s.rCl = c.take<float>(n1); s.cCl = c.take<float>(n1);
     s.ga = c.take<float>(d.BH * 4 * d.r * d.N); s.gb = c.take<float>(d.BH * 4 * d.r * d.N);
     s.P = c.take<float>(nn); s.ychain = c.take<float>(nd); s.wsig = c.take<float>(64);
+    s.Lz = c.take<float>((size_t)d.L * d.V * nn); s.rL = c.take<float>((size_t)d.L * d.V * n1); s.cL = c.take<float>((size_t)d.L * d.V * n1);
+    s.G = c.take<float>(d.dense ? 4 * nn : 0); s.X1 = c.take<float>(d.dense ? HID * nn : 0);
+    s.H2 = c.take<float>(d.k3 ? HID * nn : 0); s.X3 = c.take<float>(d.k3 ? HID * nn : 0);
     if (total) *total = c.off;
     return s;
 }
@@ -69,7 +95,13 @@ struct EwWork {
     float *drS, *dcS;              // (V,BH,N)
     float *drCr, *dcCr, *drCl, *dcCl;
     float *dQe, *dKc, *dV0, *dVL;
+    float *dZ, *DX1, *DX3;         // dense head: (4,BH,N,LD), (HID,BH,N,LD) x2
+    float *dSf, *dCrf, *dClf;      // gradients reaching S_v / Cr / Cl through per-edge features: (V,BH,N,LD), (BH,N,LD) x2
+    float *dLz;                    // (L*V,BH,N,LD)
+    float *drL, *dcL;              // low-rank head: gradients of the lens planes' row / col means (L*V,BH,N)
+    float *part;                   // [PR_BLOCKS][PR_MAXOUT] partial sums of the weight-gradient reductions
 };
+constexpr int PR_BLOCKS = 512, PR_MAXOUT = HID * (HID * 9 + 1);   // largest reduction: dW3 | db3
 static EwWork ew_carve_work(void *p, const EwDims &d, size_t *total) {
     Carver c(p);
     EwWork w;
@@ -83,6 +115,12 @@ static EwWork ew_carve_work(void *p, const EwDims &d, size_t *total) {
     w.drCr = c.take<float>(n1); w.dcCr = c.take<float>(n1); w.drCl = c.take<float>(n1); w.dcCl = c.take<float>(n1);
     w.dQe = c.take<float>(d.V * nd); w.dKc = c.take<float>(d.Vk * nd);
     w.dV0 = c.take<float>(nd); w.dVL = c.take<float>(nd);
+    w.dZ = c.take<float>(d.dense ? 4 * nn : 0); w.DX1 = c.take<float>(d.dense ? HID * nn : 0); w.DX3 = c.take<float>(d.k3 ? HID * nn : 0);
+    const bool edge = d.dense || d.L > 0;
+    w.dSf = c.take<float>(edge ? (size_t)d.V * nn : 0); w.dCrf = c.take<float>(d.dense ? nn : 0); w.dClf = c.take<float>(d.dense ? nn : 0);
+    w.dLz = c.take<float>((size_t)d.L * d.V * nn);
+    w.drL = c.take<float>((size_t)d.L * d.V * n1); w.dcL = c.take<float>((size_t)d.L * d.V * n1);
+    w.part = c.take<float>(edge ? (size_t)PR_BLOCKS * PR_MAXOUT : 0);
     if (total) *total = c.off;
     return w;
 }
@@ -160,7 +198,8 @@ __device__ __forceinline__ float row_feat(const EwSaved &s, const EwDims &d, int
     if (c < d.V) return (col ? s.cS : s.rS)[c * n1 + o];
     if (c < 2 * d.V) return (col ? s.rS : s.cS)[(c - d.V) * n1 + o];
     if (c == 2 * d.V) return (col ? s.cCr : s.rCr)[o];
-    return (col ? s.cCl : s.rCl)[o];
+    if (c == 2 * d.V + 1) return (col ? s.cCl : s.rCl)[o];
+    return (col ? s.cL : s.rL)[(c - 2 * d.V - 2) * n1 + o];      // lens planes l*V+v   :531-533
 }
 // a = Wr row_feat + br ; b = Wc col_feat + bc     (attention_variants.py:323-326)
 __global__ void gate_ab_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s) {
@@ -168,13 +207,105 @@ __global__ void gate_ab_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s) {
     if (idx >= d.BH * d.N) return;
     const int n = idx % d.N;
     const int64_t bh = idx / d.N;
-    float fr[2 * MAXV + 2], fc[2 * MAXV + 2];
+    float fr[MAXC], fc[MAXC];
     for (int c = 0; c < d.C; ++c) { fr[c] = row_feat(s, d, c, bh, n, false); fc[c] = row_feat(s, d, c, bh, n, true); }
     for (int o = 0; o < 4 * d.r; ++o) {
         float sa = a.br[o], sb = a.bc[o];
         for (int c = 0; c < d.C; ++c) { sa = fmaf(a.Wr[o * d.C + c], fr[c], sa); sb = fmaf(a.Wc[o * d.C + c], fc[c], sb); }
         s.ga[(bh * 4 * d.r + o) * d.N + n] = sa;
         s.gb[(bh * 4 * d.r + o) * d.N + n] = sb;
+    }
+}
+
+// ------------------------------------------------------------------ lens bank + dense gate head (MopkEdgewiseExt)
+__device__ __forceinline__ float gelu_tanh(float x) {                     // nn.GELU(approximate="tanh")  :252
+    return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+    const float t = tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x));
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * 0.7978845608028654f * (1.f + 3.f * 0.044715f * x * x);
+}
+// wave per row: row means of a stack of (rows, N) planes
+__global__ void rowmean_kernel(const float *in, float *rowmean, int64_t rows, int N, int LD) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float sm = 0.f;
+    for (int j = lane; j < N; j += 64) sm += in[row * LD + j];
+    sm = wave_sum(sm);
+    if (lane == 0) rowmean[row] = sm / N;
+}
+// Lz[l*V+v] = depthwise 3x3 cross-correlation of S_v, dilation = padding = dil[l]   :430-436, :526-528
+__global__ void lens_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N, lv = blockIdx.z, l = lv / d.V, v = lv % d.V, dl = d.dil[l];
+    const int64_t pl = (int64_t)d.N * d.LD, bh = blockIdx.y;
+    const float *Sv = s.S + (v * d.BH + bh) * pl;
+    float acc = 0.f;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const int ii = i + (a - 1) * dl, jj = j + (b - 1) * dl;
+            if (ii >= 0 && ii < d.N && jj >= 0 && jj < d.N) acc = fmaf(e.lens_w[(lv * 3 + a) * 3 + b], Sv[(int64_t)ii * d.LD + jj], acc);
+        }
+    s.Lz[(lv * d.BH + bh) * pl + (int64_t)i * d.LD + j] = acc;
+}
+// per-edge feature vector [S_v(i,j), S_v(j,i), Cr, Cl, lens]   :522-534
+__device__ __forceinline__ float edge_feat(const EwDims &d, const EwSaved &s, int c, int64_t bh, int i, int j) {
+    const int64_t pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
+    if (c < d.V) return s.S[c * nn + o];
+    if (c < 2 * d.V) return s.S[(c - d.V) * nn + bh * pl + (int64_t)j * d.LD + i];
+    if (c == 2 * d.V) return s.Cr[o];
+    if (c == 2 * d.V + 1) return s.Cl[o];
+    return s.Lz[(c - 2 * d.V - 2) * nn + o];
+}
+// conv1 (1x1, C->16) + GELU [+ GELU for use_k3, :315-316]; without k3 also conv2 + sigmoid   :312-318
+__global__ void dense_gate_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N;
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
+    float f[MAXC], h[HID];
+    for (int c = 0; c < d.C; ++c) f[c] = edge_feat(d, s, c, bh, i, j);
+    for (int k = 0; k < HID; ++k) {
+        float x = e.b1[k];
+        for (int c = 0; c < d.C; ++c) x = fmaf(e.W1[k * d.C + c], f[c], x);
+        s.X1[k * nn + o] = x;
+        h[k] = gelu_tanh(x);
+    }
+    if (d.k3) {
+        for (int k = 0; k < HID; ++k) s.H2[k * nn + o] = gelu_tanh(h[k]);
+    } else {
+        for (int g = 0; g < 4; ++g) {
+            float z = e.b2[g];
+            for (int k = 0; k < HID; ++k) z = fmaf(e.W2[g * HID + k], h[k], z);
+            s.G[g * nn + o] = sigmoidf_(z);
+        }
+    }
+}
+// use_k3: mid3 (3x3, 16->16, pad 1) on H2, then conv2 + sigmoid
+__global__ void dense_k3_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N;
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
+    float x3[HID];
+    for (int k = 0; k < HID; ++k) x3[k] = e.b3[k];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const int ii = i + a - 1, jj = j + b - 1;
+            if (ii < 0 || ii >= d.N || jj < 0 || jj >= d.N) continue;
+            const int64_t q = bh * pl + (int64_t)ii * d.LD + jj;
+            for (int c = 0; c < HID; ++c) {
+                const float hv = s.H2[c * nn + q];
+                for (int k = 0; k < HID; ++k) x3[k] = fmaf(e.W3[((k * HID + c) * 3 + a) * 3 + b], hv, x3[k]);
+            }
+        }
+    for (int k = 0; k < HID; ++k) s.X3[k * nn + o] = x3[k];
+    for (int g = 0; g < 4; ++g) {
+        float z = e.b2[g];
+        for (int k = 0; k < HID; ++k) z = fmaf(e.W2[g * HID + k], x3[k], z);
+        s.G[g * nn + o] = sigmoidf_(z);
     }
 }
 
@@ -188,6 +319,16 @@ __device__ __forceinline__ void gates_at(float G[4], const RowGates &g, const fl
         float z = 0.f;
         for (int k = 0; k < r; ++k) z = fmaf(g.a[q][k], gb_bh[(q * r + k) * N + j], z);
         G[q] = sigmoidf_(z);
+    }
+}
+// gates of edge (row, j): dense head reads the materialised maps, low-rank head evaluates sigmoid(a.b)
+__device__ __forceinline__ void edge_gates(float G[4], const EwDims &d, const EwSaved &s, const RowGates &g, const float *gb_bh,
+                                           int64_t row, int j) {
+    if (d.dense) {
+        const int64_t nn = d.BH * (int64_t)d.N * d.LD;
+        for (int q = 0; q < 4; ++q) G[q] = s.G[q * nn + row * d.LD + j];
+    } else {
+        gates_at(G, g, gb_bh, d.r, d.N, j);
     }
 }
 // per-element view statistics: S0, O = sum_{v>=1} S_v, lse over views
@@ -208,7 +349,7 @@ __global__ void mix_fwd_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s) {
     const int i = row % d.N;
     const int64_t bh = row / d.N;
     RowGates rg;
-    load_row_gates(rg, s.ga + bh * 4 * d.r * d.N, d.r, d.N, i);
+    if (!d.dense) load_row_gates(rg, s.ga + bh * 4 * d.r * d.N, d.r, d.N, i);
     const float *gb = s.gb + bh * 4 * d.r * d.N;
     const int64_t vstride = d.BH * (int64_t)d.N * d.LD;
     const float nb = a.beta_not / (float)max(1, d.V - 1);
@@ -217,7 +358,7 @@ __global__ void mix_fwd_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s) {
     for (int j = lane; j < d.N; j += 64) {
         float sv[MAXV], O, lse, G[4];
         view_stats(s.S, vstride, row * d.LD + j, d.V, sv, O, lse);
-        gates_at(G, rg, gb, d.r, d.N, j);
+        edge_gates(G, d, s, rg, gb, row, j);
         const float cr = s.Cr[row * d.LD + j];
         const float sm = sv[0] + G[0] * O + G[1] * (lse - sv[0]) - G[2] * (nb * O) + G[3] * cr;
         P[j] = sm; mx = fmaxf(mx, sm);
@@ -278,7 +419,7 @@ __global__ void mix_bwd_rows_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwW
     for (int j = lane; j < d.N; j += 64) dot += P[j] * dP[j];
     dot = wave_sum(dot);
     RowGates rg;
-    load_row_gates(rg, s.ga + bh * 4 * d.r * d.N, d.r, d.N, i);
+    if (!d.dense) load_row_gates(rg, s.ga + bh * 4 * d.r * d.N, d.r, d.N, i);
     const float *gb = s.gb + bh * 4 * d.r * d.N;
     const int64_t vstride = d.BH * (int64_t)d.N * d.LD;
     const float nb = a.beta_not / (float)max(1, d.V - 1);
@@ -289,13 +430,15 @@ __global__ void mix_bwd_rows_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwW
         dP[j] = dsm;
         float sv[MAXV], O, lse, G[4], tg[4];
         view_stats(s.S, vstride, row * d.LD + j, d.V, sv, O, lse);
-        gates_at(G, rg, gb, d.r, d.N, j);
+        edge_gates(G, d, s, rg, gb, row, j);
         gate_terms(tg, sv, O, lse, nb, s.Cr[row * d.LD + j]);
         for (int q = 0; q < 4; ++q) {
             const float dz = dsm * tg[q] * G[q] * (1.f - G[q]);
-            for (int k = 0; k < d.r; ++k) da[q][k] = fmaf(dz, gb[(q * d.r + k) * d.N + j], da[q][k]);
+            if (d.dense) w.dZ[q * vstride + row * d.LD + j] = dz;      // dense head: the pre-sigmoid gradient map goes to the head's backward
+            else for (int k = 0; k < d.r; ++k) da[q][k] = fmaf(dz, gb[(q * d.r + k) * d.N + j], da[q][k]);
         }
     }
+    if (d.dense) return;
     for (int q = 0; q < 4; ++q)
         for (int k = 0; k < d.r; ++k) {
             const float v = wave_sum(da[q][k]);
@@ -334,7 +477,7 @@ __global__ void gate_ab_bwd_kernel(MopkEdgewiseArgs a, EwDims d, EwWork w) {
     if (idx >= d.BH * d.N) return;
     const int n = idx % d.N;
     const int64_t bh = idx / d.N;
-    float drow[2 * MAXV + 2], dcol[2 * MAXV + 2];
+    float drow[MAXC], dcol[MAXC];
     for (int c = 0; c < d.C; ++c) { drow[c] = 0.f; dcol[c] = 0.f; }
     for (int o = 0; o < 4 * d.r; ++o) {
         const float va = w.da[(bh * 4 * d.r + o) * d.N + n], vb = w.db[(bh * 4 * d.r + o) * d.N + n];
@@ -347,6 +490,7 @@ __global__ void gate_ab_bwd_kernel(MopkEdgewiseArgs a, EwDims d, EwWork w) {
     }
     w.drCr[idx] = drow[2 * d.V]; w.dcCr[idx] = dcol[2 * d.V];
     w.drCl[idx] = drow[2 * d.V + 1]; w.dcCl[idx] = dcol[2 * d.V + 1];
+    for (int lv = 0; lv < d.L * d.V; ++lv) { w.drL[lv * n1 + idx] = drow[2 * d.V + 2 + lv]; w.dcL[lv * n1 + idx] = dcol[2 * d.V + 2 + lv]; }
 }
 // block per (o, c|bias, row|col): dW[o,c] = sum_{bh,n} d{a,b}[bh,o,n] feat[bh,c,n]
 __global__ void gate_w_bwd_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwWork w) {
@@ -375,6 +519,15 @@ __global__ void dchain_seed_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwWo
     const int lane = threadIdx.x & 63;
     const int i = row % d.N;
     const int64_t bh = row / d.N;
+    if (d.dense) {                                   // per-edge feature gradients replace the mean terms
+        const int64_t nn = d.BH * (int64_t)d.N * d.LD;
+        for (int j = lane; j < d.N; j += 64) {
+            const int64_t off = row * d.LD + j;
+            w.dCf[off] += (w.dP[off] * s.G[3 * nn + off] + w.dCrf[off]) * expf(-s.Cr[off]);
+            w.dCb[off] = w.dClf[off] * expf(-s.Cl[off]);
+        }
+        return;
+    }
     const float *ga = s.ga + bh * 4 * d.r * d.N, *gb = s.gb + bh * 4 * d.r * d.N;
     float a3[MAXR];
     for (int k = 0; k < MAXR; ++k) a3[k] = k < d.r ? ga[(3 * d.r + k) * d.N + i] : 0.f;
@@ -407,20 +560,221 @@ __global__ void ds_final_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwWork 
     for (int j = lane; j < d.N; j += 64) dot += A[j] * dA[j];
     dot = wave_sum(dot);
     RowGates rg;
-    load_row_gates(rg, s.ga + bh * 4 * d.r * d.N, d.r, d.N, i);
+    if (!d.dense) load_row_gates(rg, s.ga + bh * 4 * d.r * d.N, d.r, d.N, i);
     const float *gb = s.gb + bh * 4 * d.r * d.N;
     const float nb = a.beta_not / (float)max(1, d.V - 1);
     const float invN = 1.f / d.N;
-    const float ri = w.drS[v * rows_per_v + row] * invN;
+    const float ri = d.dense ? 0.f : w.drS[v * rows_per_v + row] * invN;
+    const bool edge = d.dense || d.L > 0;            // gradients that reach S_v through per-edge features (dense head, lens bank)
     for (int j = lane; j < d.N; j += 64) {
         float sv[MAXV], O, lse, G[4];
         view_stats(s.S, vstride, row * d.LD + j, d.V, sv, O, lse);
-        gates_at(G, rg, gb, d.r, d.N, j);
+        edge_gates(G, d, s, rg, gb, row, j);
         const float pi = expf(sv[v] - lse);
         const float coef = v == 0 ? (1.f - G[1] + G[1] * pi) : (G[0] - nb * G[2] + G[1] * pi);
-        dA[j] = A[j] * (dA[j] - dot) + w.dP[row * d.LD + j] * coef + ri + w.dcS[v * rows_per_v + bh * d.N + j] * invN;
+        float t = A[j] * (dA[j] - dot) + w.dP[row * d.LD + j] * coef + ri;
+        if (!d.dense) t += w.dcS[v * rows_per_v + bh * d.N + j] * invN;
+        if (edge) t += w.dSf[v * vstride + row * d.LD + j];
+        dA[j] = t;
     }
 }
+// ---- dense head backward (per pixel) ----
+// d last = W2^T dZ ; without k3: dX1 = d last * gelu'(X1)
+__global__ void dense_bwd_last_kernel(EwDims d, EwSaved s, EwWork w, EwExt e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N;
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
+    float dz[4];
+    for (int g = 0; g < 4; ++g) dz[g] = w.dZ[g * nn + o];
+    for (int k = 0; k < HID; ++k) {
+        float dl = 0.f;
+        for (int g = 0; g < 4; ++g) dl = fmaf(e.W2[g * HID + k], dz[g], dl);
+        if (d.k3) w.DX3[k * nn + o] = dl;
+        else w.DX1[k * nn + o] = dl * gelu_tanh_grad(s.X1[k * nn + o]);
+    }
+}
+// use_k3: dH2 = conv_transpose(dX3, W3) ; dX1 = dH2 * gelu'(gelu(X1)) * gelu'(X1)
+__global__ void dense_k3_bwd_kernel(EwDims d, EwSaved s, EwWork w, EwExt e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N;
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
+    float dh[HID];
+    for (int c = 0; c < HID; ++c) dh[c] = 0.f;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const int ii = i - (a - 1), jj = j - (b - 1);
+            if (ii < 0 || ii >= d.N || jj < 0 || jj >= d.N) continue;
+            const int64_t q = bh * pl + (int64_t)ii * d.LD + jj;
+            for (int k = 0; k < HID; ++k) {
+                const float g = w.DX3[k * nn + q];
+                for (int c = 0; c < HID; ++c) dh[c] = fmaf(e.W3[((k * HID + c) * 3 + a) * 3 + b], g, dh[c]);
+            }
+        }
+    for (int c = 0; c < HID; ++c) {
+        const float x1 = s.X1[c * nn + o];
+        w.DX1[c * nn + o] = dh[c] * gelu_tanh_grad(gelu_tanh(x1)) * gelu_tanh_grad(x1);
+    }
+}
+// d feat = W1^T dX1 scattered to its sources: S_v(i,j), S_v(j,i) (transposed read), Cr, Cl, lens planes
+__global__ void dense_bwd_feat_kernel(EwDims d, EwWork w, EwExt e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N;
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl;
+    const int64_t o = bh * pl + (int64_t)i * d.LD + j, ot = bh * pl + (int64_t)j * d.LD + i;
+    float g1[HID], g2[HID];
+    for (int k = 0; k < HID; ++k) { g1[k] = w.DX1[k * nn + o]; g2[k] = w.DX1[k * nn + ot]; }
+    for (int v = 0; v < d.V; ++v) {
+        float t = 0.f;
+        for (int k = 0; k < HID; ++k) t = fmaf(e.W1[k * d.C + v], g1[k], fmaf(e.W1[k * d.C + d.V + v], g2[k], t));
+        w.dSf[v * nn + o] = t;
+    }
+    float tr = 0.f, tl = 0.f;
+    for (int k = 0; k < HID; ++k) { tr = fmaf(e.W1[k * d.C + 2 * d.V], g1[k], tr); tl = fmaf(e.W1[k * d.C + 2 * d.V + 1], g1[k], tl); }
+    w.dCrf[o] = tr; w.dClf[o] = tl;
+    for (int lv = 0; lv < d.L * d.V; ++lv) {
+        float t = 0.f;
+        for (int k = 0; k < HID; ++k) t = fmaf(e.W1[k * d.C + 2 * d.V + 2 + lv], g1[k], t);
+        w.dLz[lv * nn + o] = t;
+    }
+}
+// low-rank head + lens bank: the head only saw the planes' means -> dLz(i,j) = (drL_i + dcL_j) / N
+__global__ void lens_dl_lowrank_kernel(EwDims d, EwWork w) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N, lv = blockIdx.z;
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, n1 = d.BH * d.N;
+    w.dLz[(lv * d.BH + bh) * pl + (int64_t)i * d.LD + j] = (w.drL[lv * n1 + bh * d.N + i] + w.dcL[lv * n1 + bh * d.N + j]) / d.N;
+}
+// dSf_v (+)= sum_l conv_transpose(dLz[l,v], lens_w[l,v])
+__global__ void lens_bwd_kernel(EwDims d, EwWork w, EwExt e) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N, v = blockIdx.z;
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
+    float acc = d.dense ? w.dSf[v * nn + o] : 0.f;
+    for (int l = 0; l < d.L; ++l) {
+        const int lv = l * d.V + v, dl = d.dil[l];
+        const float *g = w.dLz + lv * nn + bh * pl;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const int ii = i - (a - 1) * dl, jj = j - (b - 1) * dl;
+                if (ii >= 0 && ii < d.N && jj >= 0 && jj < d.N) acc = fmaf(e.lens_w[(lv * 3 + a) * 3 + b], g[(int64_t)ii * d.LD + jj], acc);
+            }
+    }
+    w.dSf[v * nn + o] = acc;
+}
+// dlens_w[lv,a,b] = sum dLz[lv](i,j) S_v(i+(a-1)d, j+(b-1)d): block (lv, chunk) -> 9 partial sums
+__global__ void lens_w_bwd_kernel(EwDims d, EwSaved s, EwWork w) {
+    __shared__ float red[9][256];
+    const int lv = blockIdx.x, l = lv / d.V, v = lv % d.V, dl = d.dil[l];
+    const int64_t pl = (int64_t)d.N * d.LD, nn = d.BH * pl, total = d.BH * d.N * d.N;
+    float acc[9];
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.y * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.y * 256) {
+        const int j = idx % d.N, i = (idx / d.N) % d.N;
+        const int64_t bh = idx / ((int64_t)d.N * d.N);
+        const float g = w.dLz[lv * nn + bh * pl + (int64_t)i * d.LD + j];
+        const float *Sv = s.S + v * nn + bh * pl;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                const int ii = i + (a - 1) * dl, jj = j + (b - 1) * dl;
+                if (ii >= 0 && ii < d.N && jj >= 0 && jj < d.N) acc[a * 3 + b] = fmaf(g, Sv[(int64_t)ii * d.LD + jj], acc[a * 3 + b]);
+            }
+    }
+    for (int t = 0; t < 9; ++t) red[t][threadIdx.x] = acc[t];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) for (int t = 0; t < 9; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) w.part[((int64_t)lv * gridDim.y + blockIdx.y) * 9 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ void lens_w_final_kernel(const float *part, float *out, int nlv, int nchunk) {      // fixed-order sum over chunks
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nlv * 9) return;
+    const int lv = o / 9, t = o % 9;
+    float sm = 0.f;
+    for (int c = 0; c < nchunk; ++c) sm += part[((int64_t)lv * nchunk + c) * 9 + t];
+    out[o] = sm;
+}
+
+// ---- weight-gradient reductions: out[a*nB + b] = sum over all pixels of A_a * B_b (last B channel == 1 -> the bias) ----
+struct LdMaps {            // plane a of a (n,BH,N,LD) stack
+    const float *base; int64_t nn; int N, LD;
+    __device__ float operator()(int a, int64_t bh, int i, int j) const { return base[a * nn + (bh * N + i) * (int64_t)LD + j]; }
+};
+struct LdFeat1 {           // edge feature channels, then the constant 1
+    EwDims d; EwSaved s;
+    __device__ float operator()(int b, int64_t bh, int i, int j) const { return b < d.C ? edge_feat(d, s, b, bh, i, j) : 1.f; }
+};
+struct LdLast1 {           // input of conv2: X3 (use_k3) or gelu(X1); then the constant 1
+    const float *X; int64_t nn; int N, LD, k3;
+    __device__ float operator()(int b, int64_t bh, int i, int j) const {
+        if (b >= HID) return 1.f;
+        const float x = X[b * nn + (bh * N + i) * (int64_t)LD + j];
+        return k3 ? x : gelu_tanh(x);
+    }
+};
+struct LdTaps1 {           // the 3x3 neighbourhood of H2: channel c*9 + a*3 + b -> H2_c(i+a-1, j+b-1); then the constant 1
+    const float *H2; int64_t nn; int N, LD;
+    __device__ float operator()(int b, int64_t bh, int i, int j) const {
+        if (b >= HID * 9) return 1.f;
+        const int c = b / 9, t = b % 9, ii = i + t / 3 - 1, jj = j + t % 3 - 1;
+        if (ii < 0 || ii >= N || jj < 0 || jj >= N) return 0.f;
+        return H2[c * nn + (bh * N + ii) * (int64_t)LD + jj];
+    }
+};
+constexpr int PR_P = 32, PR_MAXB = HID * 9 + 1, PR_PER_T = (PR_MAXOUT + 255) / 256;
+template <typename LA, typename LB>
+__global__ void pair_reduce_kernel(EwDims d, LA la, LB lb, int nA, int nB, float *part) {
+    __shared__ float As[HID][PR_P], Bs[PR_MAXB][PR_P];
+    const int64_t total = d.BH * d.N * d.N, tiles = (total + PR_P - 1) / PR_P;
+    const int nOut = nA * nB;
+    float acc[PR_PER_T];
+    for (int k = 0; k < PR_PER_T; ++k) acc[k] = 0.f;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        for (int idx = threadIdx.x; idx < (nA + nB) * PR_P; idx += 256) {
+            const int ch = idx / PR_P, pp = idx % PR_P;
+            const int64_t pix = tile * PR_P + pp;
+            float v = 0.f;
+            if (pix < total) {
+                const int j = pix % d.N, i = (pix / d.N) % d.N;
+                const int64_t bh = pix / ((int64_t)d.N * d.N);
+                v = ch < nA ? la(ch, bh, i, j) : lb(ch - nA, bh, i, j);
+            }
+            if (ch < nA) As[ch][pp] = v; else Bs[ch - nA][pp] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < PR_PER_T; ++k) {
+            const int o = threadIdx.x + 256 * k;
+            if (o < nOut) {
+                const int ai = o / nB, bi = o % nB;
+                float t = acc[k];
+                for (int pp = 0; pp < PR_P; ++pp) t = fmaf(As[ai][pp], Bs[bi][pp], t);
+                acc[k] = t;
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < PR_PER_T; ++k) {
+        const int o = threadIdx.x + 256 * k;
+        if (o < nOut) part[(int64_t)blockIdx.x * PR_MAXOUT + o] = acc[k];
+    }
+}
+// fixed-order sum over the blocks' partials; b < nB-1 -> dW[a*(nB-1)+b], b == nB-1 -> dbias[a]
+__global__ void pair_final_kernel(const float *part, int nblk, int nA, int nB, float *dW, float *dbias) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nA * nB) return;
+    float sm = 0.f;
+    for (int g = 0; g < nblk; ++g) sm += part[(int64_t)g * PR_MAXOUT + o];
+    const int ai = o / nB, bi = o % nB;
+    if (bi < nB - 1) { if (dW) dW[ai * (nB - 1) + bi] = sm; }
+    else if (dbias) dbias[ai] = sm;
+}
+
 // block (64 x 4) per (bh, d-chunk): scatter dq/dk/dv to the caller's layout, reduce scale grads over n
 template <typename T>
 __global__ void scale_bwd_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwWork w) {
@@ -488,14 +842,16 @@ static inline GemmDesc gd(int M, int N, int K, int nb0, int nb1) {
 template <typename T>
 static int ew_generic_fwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
     const EwDims d = ew_dims(a);
-    if (d.V > MAXV || d.r > MAXR || d.V < 2 || d.r < 1) return MOPK_ERR_UNSUPPORTED;
+    if (d.V > MAXV || d.r > MAXR || d.V < 2 || d.r < 1 || d.L < 0 || d.L > MAXL) return MOPK_ERR_UNSUPPORTED;
     const EwSaved s = ew_carve_saved(a->saved, d, nullptr);
     const EwWork w = ew_carve_work(a->workspace, d, nullptr);
+    const EwExt e = ew_ext(a);
     const bool mf = a->precision == MOPK_PREC_BF16;
     const int N = d.N, dk = d.dk, LD = d.LD, V = d.V;
     const int64_t nd1 = (int64_t)N * dk, nn1 = (int64_t)N * LD, ndv = d.BH * nd1, nnv = d.BH * nn1;
     const int64_t tot = d.BH * nd1;
     const int BHi = (int)d.BH;
+    const dim3 pix((N * N + 255) / 256, BHi);        // thread per edge (i,j) of one (b,h)
     hipLaunchKernelGGL((ew_prep_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, *a, d, s);
     MOPK_CHECK_LAUNCH();
     {   // S_v = Qe_v K^T                                                :500-503
@@ -526,7 +882,20 @@ static int ew_generic_fwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
     hipLaunchKernelGGL(log_rows_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, Cb, s.Cl, s.rCl, rows1, N, LD);     // :521
     hipLaunchKernelGGL(colmean_kernel, dim3((N + 255) / 256, BHi), dim3(256), 0, st, s.Cr, s.cCr, N, LD);
     hipLaunchKernelGGL(colmean_kernel, dim3((N + 255) / 256, BHi), dim3(256), 0, st, s.Cl, s.cCl, N, LD);
-    hipLaunchKernelGGL(gate_ab_kernel, dim3((rows1 + 255) / 256), dim3(256), 0, st, *a, d, s);                        // :325-326
+    if (d.L > 0) {                                                                                                    // :523-533
+        const int LV = d.L * V;
+        hipLaunchKernelGGL(lens_fwd_kernel, dim3(pix.x, BHi, LV), dim3(256), 0, st, d, s, e);
+        if (!d.dense) {
+            hipLaunchKernelGGL(rowmean_kernel, dim3((LV * rows1 + 3) / 4), dim3(256), 0, st, s.Lz, s.rL, LV * rows1, N, LD);
+            hipLaunchKernelGGL(colmean_kernel, dim3((N + 255) / 256, LV * BHi), dim3(256), 0, st, s.Lz, s.cL, N, LD);
+        }
+    }
+    if (d.dense) {                                                                                                    // :312-318
+        hipLaunchKernelGGL(dense_gate_fwd_kernel, pix, dim3(256), 0, st, d, s, e);
+        if (d.k3) hipLaunchKernelGGL(dense_k3_fwd_kernel, pix, dim3(256), 0, st, d, s, e);
+    } else {
+        hipLaunchKernelGGL(gate_ab_kernel, dim3((rows1 + 255) / 256), dim3(256), 0, st, *a, d, s);                    // :325-326
+    }
     hipLaunchKernelGGL(mix_fwd_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, *a, d, s);                            // :537-551
     MOPK_CHECK_LAUNCH();
     {   // y_base = P V0 ; y_chain = A0(A1(...(A_{V-1} VL))) = Cf VL      :554-560
@@ -546,14 +915,16 @@ static int ew_generic_fwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
 template <typename T>
 static int ew_generic_bwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
     const EwDims d = ew_dims(a);
-    if (d.V > MAXV || d.r > MAXR || d.V < 2 || d.r < 1) return MOPK_ERR_UNSUPPORTED;
+    if (d.V > MAXV || d.r > MAXR || d.V < 2 || d.r < 1 || d.L < 0 || d.L > MAXL) return MOPK_ERR_UNSUPPORTED;
     const EwSaved s = ew_carve_saved(a->saved, d, nullptr);
     const EwWork w = ew_carve_work(a->workspace, d, nullptr);
+    const EwExt e = ew_ext(a);
     const bool mf = a->precision == MOPK_PREC_BF16;
     const int N = d.N, dk = d.dk, LD = d.LD, V = d.V;
     const int64_t nd1 = (int64_t)N * dk, nn1 = (int64_t)N * LD, ndv = d.BH * nd1, nnv = d.BH * nn1;
     const int64_t tot = d.BH * nd1, rows1 = d.BH * N, rowsV = (int64_t)V * rows1;
     const int BHi = (int)d.BH;
+    const dim3 pix((N * N + 255) / 256, BHi);
     const float *Cf = s.T + (V - 2) * nnv;
     hipLaunchKernelGGL((prep_dy_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, *a, d, w.dyc);
     hipLaunchKernelGGL(dlogit_kernel, dim3(BHi), dim3(256), 0, st, w.dyc, s.ychain, s.wsig, a->dlogit_part, nd1);
@@ -575,9 +946,36 @@ static int ew_generic_bwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
         RET_IF(bgemm(h, mf, st));
     }
     hipLaunchKernelGGL(mix_bwd_rows_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, *a, d, s, w);
-    hipLaunchKernelGGL(mix_bwd_cols_kernel, dim3((N + 63) / 64, BHi), dim3(64), 0, st, *a, d, s, w);
-    hipLaunchKernelGGL(gate_ab_bwd_kernel, dim3((rows1 + 255) / 256), dim3(256), 0, st, *a, d, w);
-    hipLaunchKernelGGL(gate_w_bwd_kernel, dim3(4 * d.r, d.C + 1, 2), dim3(256), 0, st, *a, d, s, w);
+    if (d.dense) {
+        hipLaunchKernelGGL(dense_bwd_last_kernel, pix, dim3(256), 0, st, d, s, w, e);
+        if (d.k3) hipLaunchKernelGGL(dense_k3_bwd_kernel, pix, dim3(256), 0, st, d, s, w, e);
+        hipLaunchKernelGGL(dense_bwd_feat_kernel, pix, dim3(256), 0, st, d, w, e);
+        MOPK_CHECK_LAUNCH();
+        // weight gradients: all-pairs pixel reductions, partials per block then a fixed-order sum (bit-reproducible)
+        const int64_t tiles = (d.BH * N * N + PR_P - 1) / PR_P;
+        const int nblk = (int)(tiles < PR_BLOCKS ? tiles : PR_BLOCKS);
+        const LdMaps mZ{w.dZ, nnv, N, LD}, mX1{w.DX1, nnv, N, LD}, mX3{w.DX3, nnv, N, LD};
+        hipLaunchKernelGGL((pair_reduce_kernel<LdMaps, LdLast1>), dim3(nblk), dim3(256), 0, st, d, mZ,
+                           LdLast1{d.k3 ? s.X3 : s.X1, nnv, N, LD, d.k3}, 4, HID + 1, w.part);
+        hipLaunchKernelGGL(pair_final_kernel, dim3((4 * (HID + 1) + 255) / 256), dim3(256), 0, st, w.part, nblk, 4, HID + 1, e.dW2, e.db2);
+        if (d.k3) {
+            hipLaunchKernelGGL((pair_reduce_kernel<LdMaps, LdTaps1>), dim3(nblk), dim3(256), 0, st, d, mX3, LdTaps1{s.H2, nnv, N, LD}, HID, HID * 9 + 1, w.part);
+            hipLaunchKernelGGL(pair_final_kernel, dim3((HID * (HID * 9 + 1) + 255) / 256), dim3(256), 0, st, w.part, nblk, HID, HID * 9 + 1, e.dW3, e.db3);
+        }
+        hipLaunchKernelGGL((pair_reduce_kernel<LdMaps, LdFeat1>), dim3(nblk), dim3(256), 0, st, d, mX1, LdFeat1{d, s}, HID, d.C + 1, w.part);
+        hipLaunchKernelGGL(pair_final_kernel, dim3((HID * (d.C + 1) + 255) / 256), dim3(256), 0, st, w.part, nblk, HID, d.C + 1, e.dW1, e.db1);
+    } else {
+        hipLaunchKernelGGL(mix_bwd_cols_kernel, dim3((N + 63) / 64, BHi), dim3(64), 0, st, *a, d, s, w);
+        hipLaunchKernelGGL(gate_ab_bwd_kernel, dim3((rows1 + 255) / 256), dim3(256), 0, st, *a, d, w);
+        hipLaunchKernelGGL(gate_w_bwd_kernel, dim3(4 * d.r, d.C + 1, 2), dim3(256), 0, st, *a, d, s, w);
+        if (d.L > 0) hipLaunchKernelGGL(lens_dl_lowrank_kernel, dim3(pix.x, BHi, d.L * V), dim3(256), 0, st, d, w);
+    }
+    if (d.L > 0) {
+        const int LV = d.L * V, nchunk = 64;
+        hipLaunchKernelGGL(lens_bwd_kernel, dim3(pix.x, BHi, V), dim3(256), 0, st, d, w, e);
+        hipLaunchKernelGGL(lens_w_bwd_kernel, dim3(LV, nchunk), dim3(256), 0, st, d, s, w);
+        hipLaunchKernelGGL(lens_w_final_kernel, dim3((LV * 9 + 63) / 64), dim3(64), 0, st, w.part, e.dlens_w, LV, nchunk);
+    }
     hipLaunchKernelGGL(dchain_seed_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, *a, d, s, w);
     MOPK_CHECK_LAUNCH();
     // chain backward.  T_m = T_{m-1} A_m : dA_m += T_{m-1}^T D ; D <- D A_m^T ; dA_0 += D

@@ -12,9 +12,11 @@ checkpoints load with `load_state_dict` and call sites need no change:
 
 Only the Linear projections run in PyTorch (hipBLASLt); everything between the
 qkv projection and the output projection is one C-ABI call (mop_amd/ops.py).
-Variants the kernels do not cover yet raise NotImplementedError instead of
-silently decomposing: dense gate head / use_k3 (a8), lens banks (a11), masked
-Edgewise (NaN in the reference, SURVEY.md 8a note), CrossViewMixerMSA (8f rank 3).
+The dense gate head (use_k3 included) and the S lens bank run inside the library's
+generic path; the Q/K lens bank's depthwise token convolutions (:472-498) are torch
+ops feeding per-view q/k to the same core.  Variants the kernels do not cover raise
+NotImplementedError instead of silently decomposing: masked Edgewise (NaN in the
+reference, SURVEY.md 8a note), attention dropout in training, CrossViewMixerMSA (8f rank 3).
 """
 from __future__ import annotations
 
@@ -40,9 +42,8 @@ class EdgewiseGateHead(nn.Module):
     """Parameters of the per-edge gate head (reference :234-309).
 
     low-rank mode: row_proj / col_proj Conv1d(in_ch, 4*rank, 1) consumed by the
-    kernels as (4r, C) matrices.  dense mode: conv1 / [mid3] / conv2 are created
-    with the reference's names and presets so checkpoints load, but the dense
-    kernels are not built yet.
+    kernels as (4r, C) matrices.  dense mode: conv1 / [mid3] / conv2 with the
+    reference's names and presets, consumed as (16,C) / (16,16,3,3) / (4,16).
     """
 
     def __init__(self, in_ch: int, hidden: int = 16, use_k3: bool = False, gate_mode: str = "dense",
@@ -140,19 +141,46 @@ class EdgewiseMSA(nn.Module):
             raise NotImplementedError(
                 "EdgewiseMSA with attn_mask: the reference returns NaN for any blocking mask "
                 "(SURVEY.md 8a note); not supported by the kernels")
-        if self.edge_head.gate_mode != "lowrank":
-            raise NotImplementedError("EdgewiseMSA gate_mode='dense' kernels are not built yet (8f rank 2)")
-        if self.use_lens_bank or self.use_lens_bank_qk:
-            raise NotImplementedError("EdgewiseMSA lens banks are not built yet (8f rank 2)")
+        if self.use_lens_bank and self.lens_kernel_size != 3:
+            raise ValueError("lens_kernel_size must be 3: with padding = dilation any other size changes the plane size and "
+                             "the reference's feature stack (:534) cannot be built")
         if self.training and (self.attn_drop.p > 0):
             raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+
+    def _qk_lens_views(self, qkv: torch.Tensor) -> torch.Tensor:
+        """Q/K lens bank (:472-498): depthwise dilated convolutions over the token axis of view-0 q and k build one
+        (q, k) pair per dilation.  qkv: (B,N,3,H,dk) -> packed (B,N,L,3,H,dk) for the core (v of every slot = raw v)."""
+        B, N, _, H, dk = qkv.shape
+        k_sz = self.lens_qk_kernel_size
+        q_base = qkv[:, :, 0].permute(0, 2, 1, 3) * self.q_scale[0].to(qkv.dtype)      # (B,H,N,dk)   :462
+        k_base = qkv[:, :, 1].permute(0, 2, 1, 3) * self.k_scale[0].to(qkv.dtype)
+        q_flat = q_base.reshape(B * H, dk, N)              # the reference reshapes (not transposes) to (B*H, dk, N)   :477-478
+        k_flat = k_base.reshape(B * H, dk, N)
+        slots = []
+        for i, (qc, kc) in enumerate(zip(self.q_lens, self.k_lens)):
+            q_in, k_in = q_flat, k_flat
+            if self.lens_qk_causal:
+                left = (k_sz - 1) * self.lens_qk_dilations[i]                            # :484-486
+                q_in, k_in = F.pad(q_flat, (left, 0)), F.pad(k_flat, (left, 0))
+            q_l = qc(q_in).view(B, H, dk, N).permute(0, 3, 1, 2)                         # -> (B,N,H,dk)   :491-492
+            k_l = kc(k_in).view(B, H, dk, N).permute(0, 3, 1, 2)
+            slots.append(torch.stack([q_l, k_l, qkv[:, :, 2]], dim=2))                   # (B,N,3,H,dk)
+        return torch.stack(slots, dim=2)
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._check_supported(attn_mask)
         B, N, D = x.shape
         H, dk, V = self.h, self.dk, self.n_views
         inv = 1.0 / math.sqrt(dk)
-        if self.share_qkv:
+        eh = self.edge_head
+        dense = eh.gate_mode == "dense"
+        n_s = V                                            # number of score views the core sees
+        if self.share_qkv and self.use_lens_bank_qk:
+            qkv = self._qk_lens_views(self.qkv(x).view(B, N, 3, H, dk))
+            n_s = len(self.lens_qk_dilations)
+            sqk = torch.full((n_s, H, dk), inv, device=x.device, dtype=torch.float32)
+            vs0, vsL = self.v_scale[0, :, 0], self.v_scale[min(V - 1, n_s - 1), :, 0]     # :556
+        elif self.share_qkv:
             qkv = self.qkv(x).view(B, N, 1, 3, H, dk)
             sqk = (self.q_scale * self.k_scale).squeeze(2) * inv          # (V,H,dk)
             vs0, vsL = self.v_scale[0, :, 0], self.v_scale[V - 1, :, 0]   # (H,dk)
@@ -161,10 +189,23 @@ class EdgewiseMSA(nn.Module):
             qkv = F.linear(x, w).view(B, N, V, 3, H, dk)
             sqk = torch.full((V, H, dk), inv, device=x.device, dtype=torch.float32)
             vs0 = vsL = torch.ones(H, dk, device=x.device, dtype=torch.float32)
-        eh = self.edge_head
-        y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,
-                                      eh.col_proj.weight.squeeze(-1), eh.col_proj.bias,
-                                      self.chain_value_logit, float(self.beta_not), V)
+        if not dense and not self.use_lens_bank:
+            y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,
+                                          eh.col_proj.weight.squeeze(-1), eh.col_proj.bias,
+                                          self.chain_value_logit, float(self.beta_not), n_s)
+            return self.proj_drop(self.proj(y))
+        # dense gate head and / or S lens bank: the library's generic path (MopkEdgewiseExt)
+        lens_w = torch.stack([c.weight[:, 0] for c in self.lens_bank]) if self.use_lens_bank else None   # (L,S,3,3)
+        var = ops.EdgewiseVariant(dense=dense, use_k3=dense and eh.use_k3,
+                                  lens_dilations=self.lens_dilations if self.use_lens_bank else ())
+        if dense:
+            head = (eh.conv1.weight.flatten(1), eh.conv1.bias, eh.conv2.weight.flatten(1), eh.conv2.bias)
+            W3, b3 = (eh.mid3.weight, eh.mid3.bias) if eh.use_k3 else (None, None)
+        else:
+            head = (eh.row_proj.weight.squeeze(-1), eh.row_proj.bias, eh.col_proj.weight.squeeze(-1), eh.col_proj.bias)
+            W3 = b3 = None
+        y = ops.edgewise_general_core(qkv, sqk, vs0, vsL, self.chain_value_logit, head, float(self.beta_not), n_s, var,
+                                      W3=W3, b3=b3, lens_w=lens_w)
         return self.proj_drop(self.proj(y))
 
 

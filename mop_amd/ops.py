@@ -225,6 +225,125 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
                 dlg.sum().reshape(()), None, None, None, None, None)
 
 
+class EdgewiseVariant:
+    """Static description of a non-default gate head / lens bank (MopkEdgewiseExt, generic path)."""
+
+    def __init__(self, dense: bool = False, use_k3: bool = False, lens_dilations=()):
+        self.dense, self.use_k3, self.lens_dilations = bool(dense), bool(use_k3), tuple(int(d) for d in lens_dilations)
+        if len(self.lens_dilations) > L.MAX_LENS:
+            raise ValueError(f"at most {L.MAX_LENS} lens dilations are supported")
+
+
+def _fill_ext(ext: L.EdgewiseExt, var: EdgewiseVariant, t: dict):
+    ext.gate_mode, ext.use_k3, ext.n_lens = int(var.dense), int(var.use_k3), len(var.lens_dilations)
+    for i, d in enumerate(var.lens_dilations):
+        ext.lens_dil[i] = d
+    for k in ("lens_w", "W1", "b1", "W3", "b3", "W2", "b2"):
+        if t.get(k) is not None:
+            setattr(ext, k, t[k].data_ptr())
+
+
+class _EdgewiseGeneralFn(torch.autograd.Function):
+    """EdgewiseMSA core with a dense gate head and/or an S lens bank (reference :250-272, :312-318, :425-442, :523-533).
+
+    tensor inputs: qkv, sqk, vs0, vsL, logit, head (4 tensors: low-rank Wr,br,Wc,bc | dense W1,b1,W2,b2), W3, b3, lens_w
+    (unused ones are passed as empty tensors)."""
+
+    @staticmethod
+    def forward(ctx, qkv, sqk, vs0, vsL, logit, h0, h1, h2, h3, W3, b3, lens_w, beta_not, V, prec, var):
+        _require_gpu(qkv, "EdgewiseMSA")
+        lib = L.lib()
+        B, N, Vq, _, H, dk = qkv.shape
+        qkv = qkv.contiguous()
+        dev = qkv.device
+        f = dict(sqk=_f32c(sqk), vs0=_f32c(vs0), vsL=_f32c(vsL), logit=_f32c(logit).reshape(1),
+                 h0=_f32c(h0), h1=_f32c(h1), h2=_f32c(h2), h3=_f32c(h3), W3=_f32c(W3), b3=_f32c(b3), lens_w=_f32c(lens_w))
+        a, ext = L.EdgewiseArgs(), L.EdgewiseExt()
+        a.B, a.H, a.N, a.dk, a.V = B, H, N, dk, V
+        a.r = 1 if var.dense else f["h0"].shape[0] // 4
+        a.io_dtype, a.precision, a.path, a.beta_not = _io_dtype(qkv), prec, L.PATH_GENERIC, float(beta_not)
+        _ew_views(a, qkv, "")
+        a.sqk, a.vs0, a.vsL, a.chain_logit = f["sqk"].data_ptr(), f["vs0"].data_ptr(), f["vsL"].data_ptr(), f["logit"].data_ptr()
+        if var.dense:
+            _fill_ext(ext, var, dict(lens_w=f["lens_w"] if var.lens_dilations else None, W1=f["h0"], b1=f["h1"], W2=f["h2"], b2=f["h3"],
+                                     W3=f["W3"] if var.use_k3 else None, b3=f["b3"] if var.use_k3 else None))
+        else:
+            a.Wr, a.br, a.Wc, a.bc = f["h0"].data_ptr(), f["h1"].data_ptr(), f["h2"].data_ptr(), f["h3"].data_ptr()
+            _fill_ext(ext, var, dict(lens_w=f["lens_w"] if var.lens_dilations else None))
+        a.ext = C.pointer(ext)
+        y = torch.empty(B, N, H, dk, dtype=qkv.dtype, device=dev)
+        a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
+        LAST_PATH["edgewise_fwd"] = L.PATH_GENERIC
+        saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
+        ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("edgewise_fwd"):
+            rc = lib.mopk_edgewise_fwd(C.byref(a), _stream())
+        L.check(rc, "mopk_edgewise_fwd")
+        ctx.save_for_backward(qkv, saved, *f.values())
+        ctx.keys = list(f.keys())
+        ctx.meta = (beta_not, V, prec, var, int(a.r))
+        return y.view(B, N, H * dk)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        qkv, saved, *rest = ctx.saved_tensors
+        f = dict(zip(ctx.keys, rest))
+        beta_not, V, prec, var, r = ctx.meta
+        B, N, Vq, _, H, dk = qkv.shape
+        dev = qkv.device
+        dy = dy.contiguous()
+        if dy.dtype != qkv.dtype:
+            dy = dy.to(qkv.dtype)
+        a, ext = L.EdgewiseArgs(), L.EdgewiseExt()
+        a.B, a.H, a.N, a.dk, a.V, a.r = B, H, N, dk, V, r
+        a.io_dtype, a.precision, a.path, a.beta_not = _io_dtype(qkv), prec, L.PATH_GENERIC, float(beta_not)
+        _ew_views(a, qkv, "")
+        a.sqk, a.vs0, a.vsL, a.chain_logit = f["sqk"].data_ptr(), f["vs0"].data_ptr(), f["vsL"].data_ptr(), f["logit"].data_ptr()
+        a.y = L.View4(dy.data_ptr(), N * H * dk, dk, H * dk)
+        a.dy = L.View4(dy.data_ptr(), N * H * dk, dk, H * dk)
+        dqkv = (torch.empty_like(qkv) if Vq == 1 else torch.zeros_like(qkv))
+        _ew_views(a, dqkv, "d")
+        f32 = dict(dtype=torch.float32, device=dev)
+        dsqk, dvs0, dvsL, dlg = torch.empty(B, V, H, dk, **f32), torch.empty(B, H, dk, **f32), torch.empty(B, H, dk, **f32), torch.empty(B, H, **f32)
+        a.dsqk_part, a.dvs0_part, a.dvsL_part, a.dlogit_part = dsqk.data_ptr(), dvs0.data_ptr(), dvsL.data_ptr(), dlg.data_ptr()
+        g = {k: torch.zeros_like(f[k]) for k in ("h0", "h1", "h2", "h3", "W3", "b3", "lens_w")}
+        lens = f["lens_w"] if var.lens_dilations else None
+        if var.dense:
+            _fill_ext(ext, var, dict(lens_w=lens, W1=f["h0"], b1=f["h1"], W2=f["h2"], b2=f["h3"],
+                                     W3=f["W3"] if var.use_k3 else None, b3=f["b3"] if var.use_k3 else None))
+            ext.dW1, ext.db1, ext.dW2, ext.db2 = g["h0"].data_ptr(), g["h1"].data_ptr(), g["h2"].data_ptr(), g["h3"].data_ptr()
+            if var.use_k3:
+                ext.dW3, ext.db3 = g["W3"].data_ptr(), g["b3"].data_ptr()
+        else:
+            a.Wr, a.br, a.Wc, a.bc = f["h0"].data_ptr(), f["h1"].data_ptr(), f["h2"].data_ptr(), f["h3"].data_ptr()
+            a.dWr, a.dbr, a.dWc, a.dbc = g["h0"].data_ptr(), g["h1"].data_ptr(), g["h2"].data_ptr(), g["h3"].data_ptr()
+            _fill_ext(ext, var, dict(lens_w=lens))
+        if var.lens_dilations:
+            ext.dlens_w = g["lens_w"].data_ptr()
+        a.ext = C.pointer(ext)
+        LAST_PATH["edgewise_bwd"] = L.PATH_GENERIC
+        ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("edgewise_bwd"):
+            rc = lib.mopk_edgewise_bwd(C.byref(a), _stream())
+        L.check(rc, "mopk_edgewise_bwd")
+        return (dqkv, dsqk.sum(0), dvs0.sum(0), dvsL.sum(0), dlg.sum().reshape(()), g["h0"], g["h1"], g["h2"], g["h3"],
+                g["W3"], g["b3"], g["lens_w"], None, None, None, None)
+
+
+def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float, n_views: int, variant: EdgewiseVariant,
+                          W3=None, b3=None, lens_w=None, precision: Optional[int] = None):
+    """EdgewiseMSA core for the dense gate head and/or the S lens bank.  head = (Wr, br, Wc, bc) for the low-rank head
+    with C = 2V+2+L*V input channels, or (W1 (16,C), b1, W2 (4,16), b2) for the dense head; W3/b3 with use_k3;
+    lens_w (L,V,3,3).  qkv as in edgewise_lowrank_core."""
+    prec = _prec_for(qkv.dtype) if precision is None else precision
+    e = qkv.new_zeros(0, dtype=torch.float32)
+    return _EdgewiseGeneralFn.apply(qkv, sqk, vs0, vsL, chain_logit, *head, e if W3 is None else W3, e if b3 is None else b3,
+                                    e if lens_w is None else lens_w, beta_not, n_views, prec, variant)
+
+
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,
                           n_views: int, precision: Optional[int] = None, path: Optional[int] = None):
     """qkv: (B,N,Vq,3,H,dk) with Vq in {1 (share_qkv), n_views}; returns (B,N,H*dk)."""

@@ -49,6 +49,36 @@ def test_edgewise_vs_reference_golden(name, prec, path):
             f"grad {k}: rel {rel_err(grads[k].reshape(gref[k].shape), gref[k]):.3e}"
 
 
+def _ctor_variant(meta):
+    kw = dict(dim=meta["dim"], heads=meta["heads"], n_views=meta["n_views"], share_qkv=bool(meta["share_qkv"]),
+              gate_mode=meta["gate_mode"], gate_rank=meta["gate_rank"], beta_not=meta["beta_not"], use_k3=bool(meta["use_k3"]))
+    if meta["use_lens_bank"]:
+        kw.update(use_lens_bank=True, lens_dilations=tuple(int(v) for v in meta["lens_dilations"]))
+    if meta["use_lens_bank_qk"]:
+        kw.update(use_lens_bank_qk=True, lens_qk_dilations=tuple(int(v) for v in meta["lens_qk_dilations"]),
+                  lens_qk_causal=bool(meta["lens_qk_causal"]))
+    return kw
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", golden_names("ewx_"))
+def test_edgewise_variants_vs_reference_golden(name, prec):
+    """dense gate head (+use_k3), S lens bank, Q/K lens bank: reference outputs and autograd gradients."""
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import EdgewiseMSA
+    d, params, gref, meta = load_golden(name)
+    mop_amd.set_precision(prec)
+    m = module_from_golden(EdgewiseMSA, params, **_ctor_variant(meta))
+    y, dx, grads = run_fwd_bwd(m, d["x"], d["w"])
+    tol, gtol = (TOL_FP32, GTOL_FP32) if prec == "fp32" else (TOL_BF16, GTOL_BF16)
+    assert max_abs(y, d["y"]) <= tol, f"y max-abs {max_abs(y, d['y']):.3e}"
+    assert rel_err(dx, d["dx"]) <= gtol, f"dx rel {rel_err(dx, d['dx']):.3e}"
+    check_grads(grads, gref, gtol, floor=1e-3 if prec == "fp32" else 1e-2)
+    if meta["gate_mode"] == "dense" or meta["use_lens_bank"]:
+        assert ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_GENERIC
+
+
 @pytest.mark.parametrize("shape", [(3, 17, 64, 4, 3, 2), (2, 64, 128, 2, 5, 4), (1, 197, 128, 2, 5, 4),
                                    (2, 100, 64, 4, 2, 1), (1, 224, 64, 1, 4, 8), (1, 1, 32, 2, 2, 2)])
 def test_edgewise_vs_oracle_seeded(shape):

@@ -87,6 +87,34 @@ def test_unsupported_variants_raise_instead_of_falling_back():
     from mop_amd.nn import EdgewiseMSA
     x = torch.randn(1, 8, 64)
     with pytest.raises(NotImplementedError):
-        EdgewiseMSA(64, 4, gate_mode="dense")(x)
-    with pytest.raises(NotImplementedError):
         EdgewiseMSA(64, 4, gate_mode="lowrank", share_qkv=True)(x, attn_mask=torch.ones(8, 8))
+    with pytest.raises(ValueError):      # reference: torch.stack fails for lens_kernel_size != 3 (:534)
+        EdgewiseMSA(64, 4, gate_mode="lowrank", share_qkv=True, use_lens_bank=True, lens_kernel_size=5)(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # dense head is built, but never on the CPU: no fallback path
+        EdgewiseMSA(64, 4, gate_mode="dense")(x)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(gate_mode="dense", use_k3=True, n_views=3, share_qkv=True),
+    dict(gate_mode="lowrank", gate_rank=2, n_views=3, share_qkv=True, use_lens_bank=True, lens_dilations=(1, 2)),
+    dict(gate_mode="dense", n_views=4, share_qkv=True, use_lens_bank=True, lens_dilations=(1, 2), use_lens_bank_qk=True,
+         lens_qk_dilations=(2, 3), lens_qk_causal=True),
+])
+def test_variant_state_dict_matches_golden_layout(kw):
+    """dense head / lens bank parameter names and shapes = the reference's (tests/golden ewx_* fixtures hold its state_dict)."""
+    from mop_amd.nn import EdgewiseMSA
+    m = EdgewiseMSA(64, 4, **kw)
+    sd = m.state_dict()
+    eh = "edge_head."
+    n_s = len(kw["lens_qk_dilations"]) if kw.get("use_lens_bank_qk") else kw["n_views"]
+    C = 2 * n_s + 2 + (n_s * len(kw["lens_dilations"]) if kw.get("use_lens_bank") else 0)
+    if kw["gate_mode"] == "dense":
+        assert sd[eh + "conv1.weight"].shape == (16, C, 1, 1) and sd[eh + "conv2.weight"].shape == (4, 16, 1, 1)
+        assert (eh + "mid3.weight" in sd) == bool(kw.get("use_k3"))
+        assert float(sd[eh + "conv2.bias"][0]) == -5.0
+    else:
+        assert sd[eh + "row_proj.weight"].shape == (4 * kw["gate_rank"], C, 1)
+    if kw.get("use_lens_bank"):
+        assert sd["lens_bank.1.weight"].shape == (n_s, 1, 3, 3)
+    if kw.get("use_lens_bank_qk"):
+        assert sd["q_lens.0.weight"].shape == (16, 1, 3) and sd["k_lens.1.weight"].shape == (16, 1, 3)
