@@ -228,6 +228,38 @@ size_t mopk_sdpa_workspace_bytes(const MopkSdpaArgs *a);
 int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream);
 int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream);
 
+/* --------------------------------------------------------------------------
+ * CrossViewMixerMSA attention core.
+ * Replaces reference mop/models/attention_variants.py:90-110 (`_compute_logits`: S1, S2, S12, S21, 2x2 mix,
+ * transpose cues) and :120-153 (mask, softmax, optional per-key prior sharpening, A v1).
+ * anchor_mode: 0 = "fixed" (row clamp(fixed_k_star)), 1 = "argmax_row_sum" (argmax over the row sums of
+ * softmax(S2) -- all ~1, i.e. decided by rounding; reproduced as written), 2 = any other string (row 0).
+ * -------------------------------------------------------------------------- */
+typedef struct MopkCrossViewArgs {
+    int32_t B, H, N, dk;
+    int32_t io_dtype, precision, path;
+    int32_t causal;
+    int32_t use_prior;       /* enable_per_key_prior && prior_weight > 0   :126 */
+    int32_t anchor_mode, fixed_k_star;
+    float t1, t2;            /* transpose-cue weights; 0 when use_transpose_cues is False :106-110 */
+    float prior_weight;
+    MopkView4 q1, k1, v1, q2, k2;
+    const float *mix;        /* (2,2) fp32 on device :78 */
+    const uint8_t *mask;     /* optional, 1 = keep */
+    int64_t mask_sb, mask_sh, mask_si;
+    MopkView4 y;
+    void *saved, *workspace;
+    int32_t *k_star;         /* optional out (B,H) int32: anchor row used by the prior */
+    /* backward */
+    MopkView4 dy, dq1, dk1, dv1, dq2, dk2;
+    float *dmix_part;        /* (B,H,4) */
+} MopkCrossViewArgs;
+
+size_t mopk_crossview_saved_bytes(const MopkCrossViewArgs *a);
+size_t mopk_crossview_workspace_bytes(const MopkCrossViewArgs *a);
+int mopk_crossview_fwd(const MopkCrossViewArgs *a, void *stream);
+int mopk_crossview_bwd(const MopkCrossViewArgs *a, void *stream);
+
 /* -------------------------------------------------------------------------- */
 int mopk_version(void);
 const char *mopk_strerror(int status);

@@ -94,6 +94,20 @@ class SdpaArgs(C.Structure):
 
 
 # every symbol include/mopk.h declares: name -> (restype, argtypes)
+class CrossViewArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("dk", C.c_int32),
+        ("io_dtype", C.c_int32), ("precision", C.c_int32), ("path", C.c_int32), ("causal", C.c_int32),
+        ("use_prior", C.c_int32), ("anchor_mode", C.c_int32), ("fixed_k_star", C.c_int32),
+        ("t1", C.c_float), ("t2", C.c_float), ("prior_weight", C.c_float),
+        ("q1", View4), ("k1", View4), ("v1", View4), ("q2", View4), ("k2", View4),
+        ("mix", _fp), ("mask", _fp), ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_si", C.c_int64),
+        ("y", View4), ("saved", _fp), ("workspace", _fp), ("k_star", _fp),
+        ("dy", View4), ("dq1", View4), ("dk1", View4), ("dv1", View4), ("dq2", View4), ("dk2", View4),
+        ("dmix_part", _fp),
+    ]
+
+
 SYMBOLS = {
     "mopk_version": (C.c_int, []),
     "mopk_strerror": (C.c_char_p, [C.c_int]),
@@ -113,6 +127,10 @@ SYMBOLS = {
     "mopk_quartet_workspace_bytes": (C.c_size_t, [C.POINTER(QuartetArgs)]),
     "mopk_quartet_fwd": (C.c_int, [C.POINTER(QuartetArgs), C.c_void_p]),
     "mopk_quartet_bwd": (C.c_int, [C.POINTER(QuartetArgs), C.c_void_p]),
+    "mopk_crossview_saved_bytes": (C.c_size_t, [C.POINTER(CrossViewArgs)]),
+    "mopk_crossview_workspace_bytes": (C.c_size_t, [C.POINTER(CrossViewArgs)]),
+    "mopk_crossview_fwd": (C.c_int, [C.POINTER(CrossViewArgs), C.c_void_p]),
+    "mopk_crossview_bwd": (C.c_int, [C.POINTER(CrossViewArgs), C.c_void_p]),
     "mopk_sdpa_saved_bytes": (C.c_size_t, [C.POINTER(SdpaArgs)]),
     "mopk_sdpa_workspace_bytes": (C.c_size_t, [C.POINTER(SdpaArgs)]),
     "mopk_sdpa_fwd": (C.c_int, [C.POINTER(SdpaArgs), C.c_void_p]),

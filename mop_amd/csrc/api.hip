@@ -17,6 +17,8 @@ int sdpa_fwd(const MopkSdpaArgs *a, hipStream_t st); int sdpa_bwd(const MopkSdpa
 size_t dp_saved_bytes(const MopkDualPathArgs *a); size_t dp_ws_bytes(const MopkDualPathArgs *a);
 int dp_fwd(const MopkDualPathArgs *a, hipStream_t st); int dp_bwd(const MopkDualPathArgs *a, hipStream_t st);
 size_t qt_saved_bytes(const MopkQuartetArgs *a); size_t qt_ws_bytes(const MopkQuartetArgs *a);
+size_t cv_saved_bytes(const MopkCrossViewArgs *a); size_t cv_ws_bytes(const MopkCrossViewArgs *a);
+int cv_fwd(const MopkCrossViewArgs *a, hipStream_t st); int cv_bwd(const MopkCrossViewArgs *a, hipStream_t st);
 int qt_fwd(const MopkQuartetArgs *a, hipStream_t st); int qt_bwd(const MopkQuartetArgs *a, hipStream_t st);
 
 static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
@@ -129,6 +131,20 @@ int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream) {
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return sdpa_bwd(a, (hipStream_t)stream);
 }
+size_t mopk_crossview_saved_bytes(const MopkCrossViewArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0) ? cv_saved_bytes(a) : 0; }
+size_t mopk_crossview_workspace_bytes(const MopkCrossViewArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0) ? cv_ws_bytes(a) : 0; }
+static int cv_validate(const MopkCrossViewArgs *a, bool bwd) {
+    if (!a) return MOPK_ERR_BAD_ARG;
+    int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
+    if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !a->mix || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->anchor_mode < 0 || a->anchor_mode > 2) return MOPK_ERR_BAD_ARG;
+    if (!bwd && !v4ok(a->y)) return MOPK_ERR_BAD_ARG;
+    if (bwd && (!v4ok(a->dy) || !v4ok(a->dq1) || !v4ok(a->dk1) || !v4ok(a->dv1) || !v4ok(a->dq2) || !v4ok(a->dk2) || !a->dmix_part)) return MOPK_ERR_BAD_ARG;
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    return MOPK_OK;
+}
+int mopk_crossview_fwd(const MopkCrossViewArgs *a, void *stream) { int rc = cv_validate(a, false); return rc ? rc : cv_fwd(a, (hipStream_t)stream); }
+int mopk_crossview_bwd(const MopkCrossViewArgs *a, void *stream) { int rc = cv_validate(a, true); return rc ? rc : cv_bwd(a, (hipStream_t)stream); }
 size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2) ? dp_saved_bytes(a) : 0; }
 size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2) ? dp_ws_bytes(a) : 0; }
 int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream) {

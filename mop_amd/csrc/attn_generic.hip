@@ -2,6 +2,7 @@
 //   * plain SDPA            (reference attention_variants.py:42-46, components.py:61-64, whisper_mop.py:163-175)
 //   * MultiHopMSA dual-path (reference attention_variants.py:200-229)
 //   * Quartet causal attn   (reference quartet_attn_patch.py:88-121)
+//   * CrossViewMixerMSA     (reference attention_variants.py:90-153)
 // Contractions are bgemm (fp32 FMA or bf16 MFMA); maps live in fp32 in `saved`/`workspace`.
 // Backward formulas are the hand-derived ones pinned in oracle/{sdpa,multihop,quartet}.py.
 #include "bgemm.h"
@@ -518,6 +519,203 @@ int qt_bwd(const MopkQuartetArgs *a, hipStream_t st) {
         MOPK_CHECK_LAUNCH();
     }
     return MOPK_OK;
+}
+
+// =====================================================================  CrossViewMixerMSA
+struct CvBuf {
+    float *q1, *k1, *v1, *q2, *k2, *S1, *S2, *S12, *S21, *P, *A1, *A2, *A, *sden; int *kst;   // saved
+    float *y, *dy, *dA, *dS, *g1, *g2, *g12, *g21, *dA1, *danc, *rowt, *dq1, *dk1, *dv1, *dq2, *dk2;   // workspace
+};
+static CvBuf cv_carve(void *saved, void *ws, const Dm &d, bool prior, size_t *ns, size_t *nw) {
+    Carver cs(saved), cw(ws);
+    const size_t nd = d.BH * d.N * d.dk, nn = d.BH * (size_t)d.N * d.LD, n1 = d.BH * d.N;
+    CvBuf b;
+    b.q1 = cs.take<float>(nd); b.k1 = cs.take<float>(nd); b.v1 = cs.take<float>(nd); b.q2 = cs.take<float>(nd); b.k2 = cs.take<float>(nd);
+    b.S1 = cs.take<float>(nn); b.S2 = cs.take<float>(nn); b.S12 = cs.take<float>(nn); b.S21 = cs.take<float>(nn); b.P = cs.take<float>(nn);
+    b.A1 = cs.take<float>(prior ? nn : 0); b.A2 = cs.take<float>(prior ? nn : 0); b.A = cs.take<float>(prior ? nn : 0);
+    b.sden = cs.take<float>(prior ? n1 : 0); b.kst = cs.take<int>(d.BH);
+    b.y = cw.take<float>(nd); b.dy = cw.take<float>(nd); b.dA = cw.take<float>(nn); b.dS = cw.take<float>(nn);
+    b.g1 = cw.take<float>(nn); b.g2 = cw.take<float>(nn); b.g12 = cw.take<float>(nn); b.g21 = cw.take<float>(nn);
+    b.dA1 = cw.take<float>(prior ? nn : 0); b.danc = cw.take<float>(prior ? n1 : 0); b.rowt = cw.take<float>(prior ? n1 : 0);
+    b.dq1 = cw.take<float>(nd); b.dk1 = cw.take<float>(nd); b.dv1 = cw.take<float>(nd); b.dq2 = cw.take<float>(nd); b.dk2 = cw.take<float>(nd);
+    if (ns) *ns = cs.off; if (nw) *nw = cw.off;
+    return b;
+}
+size_t cv_saved_bytes(const MopkCrossViewArgs *a) { size_t s; cv_carve(nullptr, nullptr, mkdm(a->B, a->H, a->N, a->dk), a->use_prior != 0, &s, nullptr); return s; }
+size_t cv_ws_bytes(const MopkCrossViewArgs *a) { size_t w; cv_carve(nullptr, nullptr, mkdm(a->B, a->H, a->N, a->dk), a->use_prior != 0, nullptr, &w); return w; }
+
+// S = m11 S1 + m12 S12 + m21 S21 + m22 S2 + t1 S1^T + t2 S2^T     :105-110
+__global__ void cv_combine_kernel(CvBuf b, Dm d, const float *mix, float t1, float t2, float *out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N;
+    const int64_t base = (int64_t)blockIdx.y * d.N * d.LD, o = base + (int64_t)i * d.LD + j, ot = base + (int64_t)j * d.LD + i;
+    out[o] = mix[0] * b.S1[o] + mix[1] * b.S12[o] + mix[2] * b.S21[o] + mix[3] * b.S2[o] + t1 * b.S1[ot] + t2 * b.S2[ot];
+}
+// anchor row per (b,h)   :131-145
+__global__ void cv_anchor_kernel(CvBuf b, Dm d, int mode, int fixed, int *out_user) {
+    __shared__ float bv[256]; __shared__ int bi[256];
+    const int64_t bh = blockIdx.x;
+    int best = 0;
+    if (mode == 0) best = max(0, min(d.N - 1, fixed));
+    else if (mode == 1) {
+        float bval = -INFINITY; int bidx = 0x7fffffff;
+        for (int i = threadIdx.x; i < d.N; i += 256) {
+            const float *row = b.A2 + (bh * d.N + i) * (int64_t)d.LD;
+            float sm = 0.f;
+            for (int j = 0; j < d.N; ++j) sm += row[j];
+            if (sm > bval) { bval = sm; bidx = i; }                // strided scan keeps the smallest index among equal values
+        }
+        bv[threadIdx.x] = bval; bi[threadIdx.x] = bidx; __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) {
+                const float ov = bv[threadIdx.x + st]; const int oi = bi[threadIdx.x + st];
+                if (ov > bv[threadIdx.x] || (ov == bv[threadIdx.x] && oi < bi[threadIdx.x])) { bv[threadIdx.x] = ov; bi[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        best = bi[0];
+    }
+    if (threadIdx.x == 0) { b.kst[bh] = best; if (out_user) out_user[bh] = best; }
+}
+// A = (1-w) P + w * normalise_j(A1[i,j] * A2[k*,j])     :147-150 ; wave per row
+__global__ void cv_sharp_fwd_kernel(CvBuf b, Dm d, float pw) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.BH * d.N) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t bh = row / d.N;
+    const float *a1 = b.A1 + row * d.LD, *anc = b.A2 + (bh * d.N + b.kst[bh]) * (int64_t)d.LD, *p = b.P + row * d.LD;
+    float sm = 0.f;
+    for (int j = lane; j < d.N; j += 64) sm += a1[j] * anc[j];
+    sm = wave_sum(sm) + 1e-9f;
+    if (lane == 0) b.sden[row] = sm;
+    const float inv = 1.f / sm;
+    float *o = b.A + row * d.LD;
+    for (int j = lane; j < d.N; j += 64) o[j] = (1.f - pw) * p[j] + pw * a1[j] * anc[j] * inv;
+}
+// prior backward, wave per row: dA1 = du * anc ; g12 <- du * A1 (column-summed into d anc) ; dA <- (1-w) dA
+__global__ void cv_sharp_bwd_kernel(CvBuf b, Dm d, float pw) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.BH * d.N) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t bh = row / d.N;
+    const float *a1 = b.A1 + row * d.LD, *anc = b.A2 + (bh * d.N + b.kst[bh]) * (int64_t)d.LD;
+    float *dA = b.dA + row * d.LD;
+    const float inv = 1.f / b.sden[row];
+    float dot = 0.f;
+    for (int j = lane; j < d.N; j += 64) dot += pw * dA[j] * a1[j] * anc[j] * inv;
+    dot = wave_sum(dot);
+    for (int j = lane; j < d.N; j += 64) {
+        const float du = (pw * dA[j] - dot) * inv;
+        b.dA1[row * d.LD + j] = du * anc[j];
+        b.g12[row * d.LD + j] = du * a1[j];
+        dA[j] *= (1.f - pw);
+    }
+}
+// thread per column: danc[j] = sum_i g12[i,j] ; then (one block per bh) the softmax backward of row k* of A2
+__global__ void cv_anchor_bwd_kernel(CvBuf b, Dm d) {
+    __shared__ float red[256];
+    const int64_t bh = blockIdx.x;
+    const float *anc = b.A2 + (bh * d.N + b.kst[bh]) * (int64_t)d.LD;
+    float part = 0.f;
+    for (int j = threadIdx.x; j < d.N; j += 256) {
+        float sm = 0.f;
+        for (int i = 0; i < d.N; ++i) sm += b.g12[(bh * d.N + i) * (int64_t)d.LD + j];
+        b.danc[bh * d.N + j] = sm;
+        part += anc[j] * sm;
+    }
+    red[threadIdx.x] = part; __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+    const float dot = red[0];
+    for (int j = threadIdx.x; j < d.N; j += 256) b.rowt[bh * d.N + j] = anc[j] * (b.danc[bh * d.N + j] - dot);
+}
+// dmix_part[bh] = (sum dS S1, sum dS S12, sum dS S21, sum dS S2)
+__global__ void cv_dmix_kernel(CvBuf b, Dm d, float *out) {
+    __shared__ float red[4][256];
+    const int64_t bh = blockIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int p = threadIdx.x; p < d.N * d.N; p += 256) {
+        const int64_t o = bh * d.N * (int64_t)d.LD + (int64_t)(p / d.N) * d.LD + p % d.N;
+        const float g = b.dS[o];
+        acc[0] = fmaf(g, b.S1[o], acc[0]); acc[1] = fmaf(g, b.S12[o], acc[1]); acc[2] = fmaf(g, b.S21[o], acc[2]); acc[3] = fmaf(g, b.S2[o], acc[3]);
+    }
+    for (int q = 0; q < 4; ++q) red[q][threadIdx.x] = acc[q];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) out[bh * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+// gradients of the four score maps (already multiplied by 1/sqrt(dk)):
+// g1 = m11 dS + t1 dS^T [+ dS1 of the prior], g2 = m22 dS + t2 dS^T [+ row k*], g12 = m12 dS, g21 = m21 dS
+__global__ void cv_ds_kernel(CvBuf b, Dm d, const float *mix, float t1, float t2, float scale, int prior) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.N * d.N) return;
+    const int i = p / d.N, j = p % d.N;
+    const int64_t bh = blockIdx.y, base = bh * d.N * (int64_t)d.LD, o = base + (int64_t)i * d.LD + j, ot = base + (int64_t)j * d.LD + i;
+    const float g = b.dS[o], gt = b.dS[ot];
+    float x1 = mix[0] * g + t1 * gt, x2 = mix[3] * g + t2 * gt;
+    if (prior) {
+        x1 += b.dA1[o];                                           // dA1 holds the softmax backward of A1 at this point
+        if (i == b.kst[bh]) x2 += b.rowt[bh * d.N + j];
+    }
+    b.g1[o] = x1 * scale; b.g2[o] = x2 * scale; b.g12[o] = mix[1] * g * scale; b.g21[o] = mix[2] * g * scale;
+}
+
+int cv_fwd(const MopkCrossViewArgs *a, hipStream_t st) {
+    const Dm d = mkdm(a->B, a->H, a->N, a->dk);
+    const bool prior = a->use_prior != 0;
+    const CvBuf b = cv_carve(a->saved, a->workspace, d, prior, nullptr, nullptr);
+    const bool mf = a->precision == MOPK_PREC_BF16;
+    const float sc = 1.f / sqrtf((float)d.dk);
+    RET_IF(gather(a->io_dtype, a->q1, b.q1, d, st)); RET_IF(gather(a->io_dtype, a->k1, b.k1, d, st)); RET_IF(gather(a->io_dtype, a->v1, b.v1, d, st));
+    RET_IF(gather(a->io_dtype, a->q2, b.q2, d, st)); RET_IF(gather(a->io_dtype, a->k2, b.k2, d, st));
+    RET_IF(gemm_nt_scores(b.q1, b.k1, b.S1, d, sc, mf, st)); RET_IF(gemm_nt_scores(b.q2, b.k2, b.S2, d, sc, mf, st));     // :99-100
+    RET_IF(gemm_nt_scores(b.q1, b.k2, b.S12, d, sc, mf, st)); RET_IF(gemm_nt_scores(b.q2, b.k1, b.S21, d, sc, mf, st));   // :101-102
+    const dim3 pix((d.N * d.N + 255) / 256, (unsigned)d.BH);
+    const int64_t rows = d.BH * d.N;
+    const MaskSpec m{a->causal, a->mask, a->mask_sb, a->mask_sh, a->mask_si, nullptr, 0, 0, 0};
+    hipLaunchKernelGGL(cv_combine_kernel, pix, dim3(256), 0, st, b, d, a->mix, a->t1, a->t2, b.P);
+    hipLaunchKernelGGL(masked_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.P, b.P, d, m);                    // :124-125
+    if (prior) {
+        hipLaunchKernelGGL(masked_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.S1, b.A1, d, m);              // :129-130
+        hipLaunchKernelGGL(masked_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.S2, b.A2, d, m);
+        hipLaunchKernelGGL(cv_anchor_kernel, dim3((unsigned)d.BH), dim3(256), 0, st, b, d, a->anchor_mode, a->fixed_k_star, a->k_star);
+        hipLaunchKernelGGL(cv_sharp_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b, d, a->prior_weight);
+    }
+    MOPK_CHECK_LAUNCH();
+    RET_IF(gemm_map_vec(prior ? b.A : b.P, false, b.v1, b.y, d, 1.f, 0.f, mf, st));                                      // :152
+    return scatter(a->io_dtype, b.y, a->y, d, st);
+}
+int cv_bwd(const MopkCrossViewArgs *a, hipStream_t st) {
+    const Dm d = mkdm(a->B, a->H, a->N, a->dk);
+    const bool prior = a->use_prior != 0;
+    const CvBuf b = cv_carve(a->saved, a->workspace, d, prior, nullptr, nullptr);
+    const bool mf = a->precision == MOPK_PREC_BF16;
+    const float sc = 1.f / sqrtf((float)d.dk);
+    const int64_t rows = d.BH * d.N;
+    const dim3 pix((d.N * d.N + 255) / 256, (unsigned)d.BH);
+    RET_IF(gather(a->io_dtype, a->dy, b.dy, d, st));
+    RET_IF(gemm_nt_scores(b.dy, b.v1, b.dA, d, 1.f, mf, st));                               // dA = dy v1^T
+    RET_IF(gemm_map_vec(prior ? b.A : b.P, true, b.dy, b.dv1, d, 1.f, 0.f, mf, st));        // dv1 = A^T dy
+    if (prior) {
+        hipLaunchKernelGGL(cv_sharp_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b, d, a->prior_weight);
+        hipLaunchKernelGGL(cv_anchor_bwd_kernel, dim3((unsigned)d.BH), dim3(256), 0, st, b, d);
+        hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.A1, b.dA1, d, 1.f);
+    }
+    hipMemcpyAsync(b.dS, b.dA, sizeof(float) * d.BH * d.N * d.LD, hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.P, b.dS, d, 1.f);
+    hipLaunchKernelGGL(cv_dmix_kernel, dim3((unsigned)d.BH), dim3(256), 0, st, b, d, a->dmix_part);
+    hipLaunchKernelGGL(cv_ds_kernel, pix, dim3(256), 0, st, b, d, a->mix, a->t1, a->t2, sc, prior ? 1 : 0);
+    MOPK_CHECK_LAUNCH();
+    RET_IF(gemm_map_vec(b.g1, false, b.k1, b.dq1, d, 1.f, 0.f, mf, st)); RET_IF(gemm_map_vec(b.g12, false, b.k2, b.dq1, d, 1.f, 1.f, mf, st));
+    RET_IF(gemm_map_vec(b.g1, true, b.q1, b.dk1, d, 1.f, 0.f, mf, st)); RET_IF(gemm_map_vec(b.g21, true, b.q2, b.dk1, d, 1.f, 1.f, mf, st));
+    RET_IF(gemm_map_vec(b.g2, false, b.k2, b.dq2, d, 1.f, 0.f, mf, st)); RET_IF(gemm_map_vec(b.g21, false, b.k1, b.dq2, d, 1.f, 1.f, mf, st));
+    RET_IF(gemm_map_vec(b.g2, true, b.q2, b.dk2, d, 1.f, 0.f, mf, st)); RET_IF(gemm_map_vec(b.g12, true, b.q1, b.dk2, d, 1.f, 1.f, mf, st));
+    RET_IF(scatter(a->io_dtype, b.dq1, a->dq1, d, st)); RET_IF(scatter(a->io_dtype, b.dk1, a->dk1, d, st)); RET_IF(scatter(a->io_dtype, b.dv1, a->dv1, d, st));
+    RET_IF(scatter(a->io_dtype, b.dq2, a->dq2, d, st));
+    return scatter(a->io_dtype, b.dk2, a->dk2, d, st);
 }
 
 }  // namespace mopk

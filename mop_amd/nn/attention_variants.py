@@ -16,7 +16,7 @@ The dense gate head (use_k3 included) and the S lens bank run inside the library
 generic path; the Q/K lens bank's depthwise token convolutions (:472-498) are torch
 ops feeding per-view q/k to the same core.  Variants the kernels do not cover raise
 NotImplementedError instead of silently decomposing: masked Edgewise (NaN in the
-reference, SURVEY.md 8a note), attention dropout in training, CrossViewMixerMSA (8f rank 3).
+reference, SURVEY.md 8a note), attention dropout in training.
 """
 from __future__ import annotations
 
@@ -256,7 +256,7 @@ class MultiHopMSA(nn.Module):
 
 
 class CrossViewMixerMSA(nn.Module):
-    """Parameter-compatible placeholder (reference :51-156); kernels are SURVEY.md 8f rank 3."""
+    """Cross-view binding: four score maps mixed 2x2, transpose cues, optional per-key prior (reference :51-156)."""
 
     def __init__(self, dim: int, heads: int = 4, attn_drop: float = 0.0, proj_drop: float = 0.0,
                  use_transpose_cues: bool = True, t1: float = 0.0, t2: float = 0.0,
@@ -275,8 +275,18 @@ class CrossViewMixerMSA(nn.Module):
         self.enable_per_key_prior, self.prior_weight = bool(enable_per_key_prior), float(prior_weight)
         self.anchor_mode, self.fixed_k_star = str(anchor_mode), int(fixed_k_star)
 
-    def forward(self, x, attn_mask=None):
-        raise NotImplementedError("CrossViewMixerMSA kernels are not built yet (SURVEY.md 8f rank 3)")
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.training and self.attn_drop.p > 0:
+            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+        B, N, D = x.shape
+        a = self.qkv1(x).view(B, N, 3, self.h, self.dk)
+        b = self.qkv2(x).view(B, N, 3, self.h, self.dk)           # v2 is unused by the reference too (:98)
+        cues = self.use_transpose_cues
+        pw = self.prior_weight if (self.enable_per_key_prior and self.prior_weight > 0.0) else 0.0     # :126
+        y = ops.crossview_core(a[:, :, 0], a[:, :, 1], a[:, :, 2], b[:, :, 0], b[:, :, 1], self.mix,
+                               t1=self.t1 if cues else 0.0, t2=self.t2 if cues else 0.0, prior_weight=pw,
+                               anchor_mode=self.anchor_mode, fixed_k_star=self.fixed_k_star, attn_mask=attn_mask)
+        return self.proj_drop(self.proj(y))
 
 
 class UnifiedMSA(nn.Module):

@@ -446,6 +446,78 @@ def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False):
     return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype))
 
 
+_ANCHOR_MODES = {"fixed": 0, "argmax_row_sum": 1}          # any other string -> row 0 (reference :141-145)
+
+
+class _CrossViewFn(torch.autograd.Function):
+    """CrossViewMixerMSA core, reference attention_variants.py:90-153."""
+
+    @staticmethod
+    def forward(ctx, q1, k1, v1, q2, k2, mix, cfg, mask, causal, prec):
+        _require_gpu(q1, "CrossViewMixerMSA")
+        lib = L.lib()
+        ts = [_heads_view(t) for t in (q1, k1, v1, q2, k2)]
+        B, N, H, dk = ts[0].shape
+        dev = ts[0].device
+        mx = _f32c(mix).reshape(4)
+        a = L.CrossViewArgs()
+        a.B, a.H, a.N, a.dk = B, H, N, dk
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, L.PATH_GENERIC, int(bool(causal))
+        a.t1, a.t2, a.prior_weight, a.use_prior, a.anchor_mode, a.fixed_k_star = cfg
+        a.q1, a.k1, a.v1, a.q2, a.k2 = (_v4(t) for t in ts)
+        a.mix = mx.data_ptr()
+        m8, ms = _mask_u8(mask, B, H, N, dev)
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        y = torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev)
+        a.y = _v4(y)
+        kst = torch.zeros(B, H, dtype=torch.int32, device=dev)
+        a.k_star = kst.data_ptr()
+        saved = _bytes(lib.mopk_crossview_saved_bytes(C.byref(a)), dev)
+        ws = _bytes(lib.mopk_crossview_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("crossview_fwd"):
+            rc = lib.mopk_crossview_fwd(C.byref(a), _stream())
+        L.check(rc, "mopk_crossview_fwd")
+        LAST_PATH["crossview_k_star"] = kst
+        ctx.save_for_backward(*ts, mx, saved)
+        ctx.meta = (cfg, causal, prec, m8, ms)
+        return y.view(B, N, H * dk)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.lib()
+        *ts, mx, saved = ctx.saved_tensors
+        cfg, causal, prec, m8, ms = ctx.meta
+        B, N, H, dk = ts[0].shape
+        dev = ts[0].device
+        dy = dy.contiguous().to(ts[0].dtype).view(B, N, H, dk)
+        a = L.CrossViewArgs()
+        a.B, a.H, a.N, a.dk = B, H, N, dk
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, L.PATH_GENERIC, int(bool(causal))
+        a.t1, a.t2, a.prior_weight, a.use_prior, a.anchor_mode, a.fixed_k_star = cfg
+        a.q1, a.k1, a.v1, a.q2, a.k2 = (_v4(t) for t in ts)
+        a.mix = mx.data_ptr()
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        a.y, a.dy = _v4(dy), _v4(dy)
+        outs = [torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(5)]
+        a.dq1, a.dk1, a.dv1, a.dq2, a.dk2 = (_v4(t) for t in outs)
+        dmix = torch.empty(B, H, 4, dtype=torch.float32, device=dev)
+        a.dmix_part = dmix.data_ptr()
+        ws = _bytes(lib.mopk_crossview_workspace_bytes(C.byref(a)), dev)
+        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        with _timed("crossview_bwd"):
+            rc = lib.mopk_crossview_bwd(C.byref(a), _stream())
+        L.check(rc, "mopk_crossview_bwd")
+        return (*outs, dmix.sum((0, 1)).view(2, 2), None, None, None, None)
+
+
+def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, anchor_mode="argmax_row_sum", fixed_k_star=0,
+                   attn_mask=None, causal=False):
+    """q*,k*,v1: (B,N,H,dk) views; mix (2,2).  prior_weight = 0 disables the per-key prior.  Returns (B,N,H*dk)."""
+    cfg = (float(t1), float(t2), float(prior_weight), int(prior_weight > 0.0), _ANCHOR_MODES.get(anchor_mode, 2), int(fixed_k_star))
+    return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, _prec_for(q1.dtype))
+
+
 class _DualPathFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q1, k1, v1, q2, k2, v2, logit, gates, beta_not, hops, mask, causal, prec):

@@ -43,8 +43,9 @@ def test_struct_sizes_match_header(lib):
     prog = r'''
 #include <stdio.h>
 #include "mopk.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(MopkView4), sizeof(MopkView5),
- sizeof(MopkEdgewiseArgs), sizeof(MopkDualPathArgs), sizeof(MopkQuartetArgs), sizeof(MopkSdpaArgs), sizeof(MopkEdgewiseExt));return 0;}
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(MopkView4), sizeof(MopkView5),
+ sizeof(MopkEdgewiseArgs), sizeof(MopkDualPathArgs), sizeof(MopkQuartetArgs), sizeof(MopkSdpaArgs), sizeof(MopkEdgewiseExt),
+ sizeof(MopkCrossViewArgs));return 0;}
 '''
     with tempfile.TemporaryDirectory() as td:
         cpath = os.path.join(td, "s.c")
@@ -54,7 +55,7 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(MopkView4), sizeof
         sizes = list(map(int, subprocess.check_output([exe]).split()))
     from mop_amd import _lib
     mine = [C.sizeof(t) for t in (_lib.View4, _lib.View5, _lib.EdgewiseArgs, _lib.DualPathArgs,
-                                  _lib.QuartetArgs, _lib.SdpaArgs, _lib.EdgewiseExt)]
+                                  _lib.QuartetArgs, _lib.SdpaArgs, _lib.EdgewiseExt, _lib.CrossViewArgs)]
     assert mine == sizes
 
 

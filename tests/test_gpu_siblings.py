@@ -73,6 +73,60 @@ def test_quartet(name, prec):
     _check(*run_fwd_bwd(m, d["x"], d["w"], **fk), d, gref, prec)
 
 
+def _cv_ctor(meta):
+    return dict(dim=meta["dim"], heads=meta["heads"], use_transpose_cues=bool(meta["use_transpose_cues"]), t1=meta["t1"],
+                t2=meta["t2"], enable_per_key_prior=bool(meta["enable_per_key_prior"]), prior_weight=meta["prior_weight"],
+                anchor_mode=meta["anchor_mode"], fixed_k_star=meta["fixed_k_star"])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", golden_names("cv_"))
+def test_crossview_mixer(name, prec):
+    """CrossViewMixerMSA (reference attention_variants.py:51-156): 2x2 mix, transpose cues, masks, per-key prior."""
+    import mop_amd
+    from mop_amd import ops
+    from mop_amd.nn import CrossViewMixerMSA
+    d, params, gref, meta = load_golden(name)
+    mop_amd.set_precision(prec)
+    m = module_from_golden(CrossViewMixerMSA, params, **_cv_ctor(meta))
+    fk = {}
+    if "attn_mask" in d:
+        fk["attn_mask"] = torch.from_numpy(d["attn_mask"]).cuda()
+    out = run_fwd_bwd(m, d["x"], d["w"], **fk)
+    if "k_star" in d:
+        # anchor_mode="argmax_row_sum": argmax over row sums that are all 1 up to rounding; the comparison is only
+        # meaningful where this device's rounding picked the anchor the reference's CPU run picked
+        mine = ops.LAST_PATH["crossview_k_star"].cpu().numpy()
+        if not np.array_equal(mine, d["k_star"]):
+            pytest.skip(f"rounding-decided anchors differ from the reference's CPU run ({mine.tolist()} vs {d['k_star'].tolist()})")
+    _check(*out, d, gref, prec)
+
+
+def test_crossview_argmax_anchor_is_self_consistent():
+    """whatever row argmax_row_sum picks on this device, the result equals anchor_mode='fixed' with that row (single b,h)."""
+    import mop_amd
+    from mop_amd import ops
+    from mop_amd.nn import CrossViewMixerMSA
+    mop_amd.set_precision("fp32")
+    torch.manual_seed(3)
+    x = torch.randn(1, 40, 32, device="cuda")
+    ma = CrossViewMixerMSA(32, 1, enable_per_key_prior=True, prior_weight=0.5).cuda().eval()
+    ya = ma(x)
+    k = int(ops.LAST_PATH["crossview_k_star"][0, 0])
+    mf = CrossViewMixerMSA(32, 1, enable_per_key_prior=True, prior_weight=0.5, anchor_mode="fixed", fixed_k_star=k).cuda().eval()
+    mf.load_state_dict(ma.state_dict())
+    assert torch.equal(ya, mf(x))
+
+
+def test_unified_mode_c_runs():
+    from mop_amd.nn import UnifiedMSA
+    torch.manual_seed(0)
+    m = UnifiedMSA("C", 64, 4, t1=0.1).cuda()
+    x = torch.randn(2, 9, 64, device="cuda", requires_grad=True)
+    m(x).sum().backward()
+    assert x.grad.shape == x.shape and torch.isfinite(x.grad).all() and m.impl.mix.grad.shape == (2, 2)
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_names, load_golden
-from oracle import edgewise, multihop, quartet, sdpa
+from oracle import crossview, edgewise, multihop, quartet, sdpa
 
 TOL = dict(rtol=2e-4, atol=2e-5)
 
@@ -48,6 +48,21 @@ def test_edgewise_variants(name, dtype):
     out, cache = edgewise.module_fwd(d["x"].astype(dtype), p, meta["heads"], meta["n_views"], bool(meta["share_qkv"]),
                                      meta["beta_not"], **ewx_oracle_kwargs(meta))
     dx, grads = edgewise.module_bwd(d["w"].astype(dtype), cache)
+    _check(out, dx, grads, d, gref)
+
+
+def cv_oracle_kwargs(d, meta):
+    return dict(attn_mask=d.get("attn_mask"), use_transpose_cues=bool(meta["use_transpose_cues"]), t1=meta["t1"], t2=meta["t2"],
+                enable_per_key_prior=bool(meta["enable_per_key_prior"]), prior_weight=meta["prior_weight"],
+                anchor_mode=meta["anchor_mode"], fixed_k_star=meta["fixed_k_star"], k_star=d.get("k_star"))
+
+
+@pytest.mark.parametrize("name", golden_names("cv_"))
+def test_crossview(name):
+    d, params, gref, meta = load_golden(name)
+    p = {k: v.astype(np.float64) for k, v in params.items()}
+    out, cache = crossview.module_fwd(d["x"].astype(np.float64), p, meta["heads"], **cv_oracle_kwargs(d, meta))
+    dx, grads = crossview.module_bwd(d["w"].astype(np.float64), cache)
     _check(out, dx, grads, d, gref)
 
 

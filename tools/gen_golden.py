@@ -23,7 +23,7 @@ REF = os.environ.get("MOP_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
 sys.dont_write_bytecode = True
 
-from mop.models.attention_variants import (BaselineMSA, EdgewiseMSA,  # noqa: E402
+from mop.models.attention_variants import (BaselineMSA, CrossViewMixerMSA, EdgewiseMSA,  # noqa: E402
                                            MultiHopMSA)
 from mop.models.quartet_attn_patch import (CausalSelfAttention,  # noqa: E402
                                            TransformerConfig)
@@ -136,6 +136,41 @@ def edgewise_variant_cases():
         _save(name, _run(mod, x, extra=extra))
 
 
+def crossview_cases():
+    """CrossViewMixerMSA (attention_variants.py:51-156)."""
+    cases = [
+        # name, dim, heads, B, N, ctor kwargs, causal mask
+        ("cv_tiny_default", 64, 4, 2, 8, dict(), False),
+        ("cv_tiny_cues_fixed_prior", 64, 4, 2, 8, dict(t1=0.3, t2=-0.2, enable_per_key_prior=True, prior_weight=0.4,
+                                                      anchor_mode="fixed", fixed_k_star=3), False),
+        ("cv_mid_cues_causal_prior0", 96, 3, 2, 33, dict(t1=0.25, t2=0.1, enable_per_key_prior=True, prior_weight=0.6,
+                                                        anchor_mode="first"), True),
+        ("cv_mid_argmax_prior", 128, 2, 2, 50, dict(enable_per_key_prior=True, prior_weight=0.5), False),
+        ("cv_odd_nocues", 32, 2, 1, 6, dict(use_transpose_cues=False, t1=0.7, t2=0.7), False),
+    ]
+    for i, (name, dim, heads, B, N, kw, causal) in enumerate(cases):
+        torch.manual_seed(600 + i)
+        mod = CrossViewMixerMSA(dim, heads, **kw).eval()
+        with torch.no_grad():
+            mod.mix.add_(0.3 * torch.randn(2, 2))                 # identity init makes S12/S21 and dmix off-diagonals untested
+        x = torch.randn(B, N, dim)
+        fk, extra = {}, {}
+        if causal:
+            mask = torch.tril(torch.ones(N, N)).view(1, 1, N, N)
+            fk["attn_mask"] = mask
+            extra["attn_mask"] = mask.numpy()
+        meta = dict(kind="crossview", dim=dim, heads=heads, use_transpose_cues=kw.get("use_transpose_cues", True),
+                    t1=kw.get("t1", 0.0), t2=kw.get("t2", 0.0), enable_per_key_prior=kw.get("enable_per_key_prior", False),
+                    prior_weight=kw.get("prior_weight", 0.5), anchor_mode=kw.get("anchor_mode", "argmax_row_sum"),
+                    fixed_k_star=kw.get("fixed_k_star", 0))
+        extra.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
+        if meta["enable_per_key_prior"] and meta["anchor_mode"] == "argmax_row_sum":
+            with torch.no_grad():                                 # the anchor the reference picked (:139-140), rounding-noise dependent
+                _, _, S2, _ = mod._compute_logits(x)
+                extra["k_star"] = torch.softmax(mod._apply_mask(S2, fk.get("attn_mask")), -1).sum(-1).argmax(-1).numpy()
+        _save(name, _run(mod, x, fk, extra))
+
+
 def multihop_cases():
     cases = [
         ("mh_tiny_default", 64, 4, 2, 8, dict(), False),
@@ -205,6 +240,6 @@ def sdpa_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    groups = dict(ew=edgewise_cases, ewx=edgewise_variant_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
+    groups = dict(ew=edgewise_cases, ewx=edgewise_variant_cases, cv=crossview_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
     for name in (sys.argv[1:] or list(groups)):               # e.g. `gen_golden.py ewx` regenerates one group only
         groups[name]()
