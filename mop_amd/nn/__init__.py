@@ -5,3 +5,5 @@ from .components import (MLP, MSA, Block, DropPath, FuseExcInh, Kernels3, PatchE
                          ViewsLinear, ViTEncoder)
 from .quartet_attn_patch import CausalSelfAttention, TransformerConfig  # noqa: F401
 from .vit_mop import ViT_MoP  # noqa: F401
+from .whisper_mop import (EncoderBlock, FuseExcInh2D, Kernels2D, MoP2D, MultiheadSelfAttention,  # noqa: F401
+                          ViewsConv2D, WhisperConfig)

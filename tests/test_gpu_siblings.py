@@ -127,6 +127,52 @@ def test_unified_mode_c_runs():
     assert x.grad.shape == x.shape and torch.isfinite(x.grad).all() and m.impl.mix.grad.shape == (2, 2)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", golden_names("wh_"))
+def test_whisper_encoder_block(name, prec):
+    """Whisper-MoP EncoderBlock (non-causal MultiheadSelfAttention core in libmopk, MoP2D gate, MLP) vs the reference."""
+    import mop_amd
+    from mop_amd.nn import EncoderBlock, WhisperConfig
+    d, params, gref, meta = load_golden(name)
+    mop_amd.set_precision(prec)
+    T = d["x"].shape[1]
+    cfg = WhisperConfig(n_mels=meta["n_mels"], n_audio_ctx=T, n_embd=meta["dim"], n_head=meta["heads"], n_layer_enc=1,
+                        n_layer_dec=1, bias=bool(meta["bias"]), n_views=meta["n_views"], n_kernels=meta["n_kernels"],
+                        kernel_size=meta["kernel_size"])
+    mel = torch.from_numpy(d["mel"]).cuda()
+
+    class Wrap(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blk = EncoderBlock(cfg)
+
+        def forward(self, x):
+            return self.blk(x, mel)[0]
+
+    m = module_from_golden(Wrap, params)
+    y, dx, grads = run_fwd_bwd(m, d["x"], d["w"])
+    tol, gtol = TOL[prec]
+    assert max_abs(y, d["y"]) / float(np.abs(d["y"]).max()) <= tol
+    assert rel_err(dx, d["dx"]) <= gtol
+    check_grads(grads, gref, gtol, floor=1e-2 if prec == "bf16" else 1e-3)
+
+
+def test_whisper_self_attention_causal_bias_matches_torch():
+    """causal flag + additive attn_bias of MultiheadSelfAttention (reference :163-170) against the same math in torch."""
+    import mop_amd
+    from mop_amd.nn import MultiheadSelfAttention
+    mop_amd.set_precision("fp32")
+    torch.manual_seed(1)
+    m = MultiheadSelfAttention(64, 4, 0.0, True, causal=True).cuda().eval()
+    x = torch.randn(2, 19, 64, device="cuda")
+    bias = 0.5 * torch.randn(2, 1, 19, 19, device="cuda")
+    q, k, v = (p(x).view(2, 19, 4, 16).transpose(1, 2) for p in (m.q_proj, m.k_proj, m.v_proj))
+    att = (q @ k.transpose(-2, -1)) * m.scale
+    att = att.masked_fill(~torch.tril(torch.ones(19, 19, dtype=torch.bool, device="cuda")), float("-inf")) + bias
+    ref = m.o_proj((att.softmax(-1) @ v).transpose(1, 2).reshape(2, 19, 64))
+    assert float((m(x, attn_bias=bias) - ref).detach().abs().max()) <= 1e-4
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)

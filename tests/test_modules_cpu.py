@@ -118,3 +118,16 @@ def test_variant_state_dict_matches_golden_layout(kw):
         assert sd["lens_bank.1.weight"].shape == (n_s, 1, 3, 3)
     if kw.get("use_lens_bank_qk"):
         assert sd["q_lens.0.weight"].shape == (16, 1, 3) and sd["k_lens.1.weight"].shape == (16, 1, 3)
+
+
+@pytest.mark.parametrize("name", golden_names("wh_"))
+def test_whisper_encoder_block_state_dict(name):
+    from mop_amd.nn import EncoderBlock, WhisperConfig
+    d, params, gref, meta = load_golden(name)
+    cfg = WhisperConfig(n_mels=meta["n_mels"], n_embd=meta["dim"], n_head=meta["heads"], bias=bool(meta["bias"]),
+                        n_views=meta["n_views"], n_kernels=meta["n_kernels"], kernel_size=meta["kernel_size"])
+    sd = EncoderBlock(cfg).state_dict()
+    ref = {k[len("blk."):]: v for k, v in params.items()}
+    assert set(sd) == set(ref)
+    for k, v in ref.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k

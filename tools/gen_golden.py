@@ -28,6 +28,8 @@ from mop.models.attention_variants import (BaselineMSA, CrossViewMixerMSA, Edgew
 from mop.models.quartet_attn_patch import (CausalSelfAttention,  # noqa: E402
                                            TransformerConfig)
 
+from mop.models.whisper_mop import EncoderBlock, WhisperConfig  # noqa: E402
+
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
@@ -171,6 +173,31 @@ def crossview_cases():
         _save(name, _run(mod, x, fk, extra))
 
 
+def whisper_cases():
+    """Whisper-MoP encoder block: non-causal MultiheadSelfAttention + MoP2D mel gate + MLP (whisper_mop.py:91-124, :137-177, :250-275)."""
+    cases = [("wh_enc_tiny", 64, 4, 2, 12, 10, False), ("wh_enc_mid_bias", 96, 3, 2, 40, 16, True)]
+    for i, (name, dim, heads, B, T, n_mels, bias) in enumerate(cases):
+        torch.manual_seed(700 + i)
+        cfg = WhisperConfig(n_mels=n_mels, n_audio_ctx=T, n_embd=dim, n_head=heads, n_layer_enc=1, n_layer_dec=1, bias=bias,
+                            n_views=3, n_kernels=2, kernel_size=3)
+        blk = EncoderBlock(cfg).eval()
+        mel = torch.randn(B, 1, T, n_mels)
+
+        class Wrap(torch.nn.Module):          # the block returns (x, gate); L = sum(x * w) sees both paths
+            def __init__(self):
+                super().__init__()
+                self.blk = blk
+
+            def forward(self, x):
+                return self.blk(x, mel)[0]
+
+        x = torch.randn(B, T, dim)
+        meta = dict(kind="whisper_enc", dim=dim, heads=heads, n_mels=n_mels, bias=bias, n_views=3, n_kernels=2, kernel_size=3)
+        extra = {"meta:" + k: np.asarray(v) for k, v in meta.items()}
+        extra["mel"] = mel.numpy()
+        _save(name, _run(Wrap(), x, extra=extra))
+
+
 def multihop_cases():
     cases = [
         ("mh_tiny_default", 64, 4, 2, 8, dict(), False),
@@ -240,6 +267,6 @@ def sdpa_cases():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    groups = dict(ew=edgewise_cases, ewx=edgewise_variant_cases, cv=crossview_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
+    groups = dict(ew=edgewise_cases, ewx=edgewise_variant_cases, cv=crossview_cases, wh=whisper_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
     for name in (sys.argv[1:] or list(groups)):               # e.g. `gen_golden.py ewx` regenerates one group only
         groups[name]()
