@@ -208,6 +208,7 @@ int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream);
  * Plain scaled-dot-product attention core.
  * Replaces BaselineMSA.forward attention_variants.py:42-46, MSA.forward
  * components.py:61-64 and MultiheadSelfAttention.forward whisper_mop.py:163-175.
+ * path: MOPK_PATH_AUTO picks the fused kernels (sdpa_flash.hip: no N x N map in HBM) when they cover the call.
  * -------------------------------------------------------------------------- */
 typedef struct MopkSdpaArgs {
     int32_t B, H, N, dk;
@@ -226,7 +227,9 @@ typedef struct MopkSdpaArgs {
 size_t mopk_sdpa_saved_bytes(const MopkSdpaArgs *a);
 size_t mopk_sdpa_workspace_bytes(const MopkSdpaArgs *a);
 int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream);
-int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream);
+int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream);  /* needs q,k,v, y (forward output), dy; mask/bias as in the forward */
+/* 1 if the fused (flash-style) gfx950 kernels take this call under MOPK_PATH_AUTO: bf16 arithmetic, dk 32/64, no mask/bias tensor */
+int mopk_sdpa_fused_supported(const MopkSdpaArgs *a);
 
 /* --------------------------------------------------------------------------
  * CrossViewMixerMSA attention core.

@@ -133,6 +133,7 @@ SYMBOLS = {
     "mopk_crossview_bwd": (C.c_int, [C.POINTER(CrossViewArgs), C.c_void_p]),
     "mopk_sdpa_saved_bytes": (C.c_size_t, [C.POINTER(SdpaArgs)]),
     "mopk_sdpa_workspace_bytes": (C.c_size_t, [C.POINTER(SdpaArgs)]),
+    "mopk_sdpa_fused_supported": (C.c_int, [C.POINTER(SdpaArgs)]),
     "mopk_sdpa_fwd": (C.c_int, [C.POINTER(SdpaArgs), C.c_void_p]),
     "mopk_sdpa_bwd": (C.c_int, [C.POINTER(SdpaArgs), C.c_void_p]),
 }

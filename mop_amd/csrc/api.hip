@@ -14,6 +14,8 @@ size_t ew_fused_bwd_ws_bytes(const MopkEdgewiseArgs *a);
 int ew_fused_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
 size_t sdpa_saved_bytes(const MopkSdpaArgs *a); size_t sdpa_ws_bytes(const MopkSdpaArgs *a);
 int sdpa_fwd(const MopkSdpaArgs *a, hipStream_t st); int sdpa_bwd(const MopkSdpaArgs *a, hipStream_t st);
+int sdpa_flash_supported(const MopkSdpaArgs *a, bool bwd); size_t sdpa_flash_saved_bytes(const MopkSdpaArgs *a); size_t sdpa_flash_ws_bytes(const MopkSdpaArgs *a);
+int sdpa_flash_fwd(const MopkSdpaArgs *a, hipStream_t st); int sdpa_flash_bwd(const MopkSdpaArgs *a, hipStream_t st);
 size_t dp_saved_bytes(const MopkDualPathArgs *a); size_t dp_ws_bytes(const MopkDualPathArgs *a);
 int dp_fwd(const MopkDualPathArgs *a, hipStream_t st); int dp_bwd(const MopkDualPathArgs *a, hipStream_t st);
 size_t qt_saved_bytes(const MopkQuartetArgs *a); size_t qt_ws_bytes(const MopkQuartetArgs *a);
@@ -115,19 +117,34 @@ static int base_ok(int B, int H, int N, int dk, int io, int prec) {
     if ((io != MOPK_F32 && io != MOPK_BF16) || (prec != MOPK_PREC_FP32 && prec != MOPK_PREC_BF16)) return MOPK_ERR_BAD_ARG;
     return MOPK_OK;
 }
-size_t mopk_sdpa_saved_bytes(const MopkSdpaArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0) ? sdpa_saved_bytes(a) : 0; }
-size_t mopk_sdpa_workspace_bytes(const MopkSdpaArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0) ? sdpa_ws_bytes(a) : 0; }
+// path: AUTO = fused flash kernels when they cover the call (bf16 arithmetic, dk 32/64, no mask/bias tensor), else generic
+static bool sdpa_use_flash(const MopkSdpaArgs *a, bool bwd) {
+    return a->path != MOPK_PATH_GENERIC && sdpa_flash_supported(a, bwd);
+}
+int mopk_sdpa_fused_supported(const MopkSdpaArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0) ? sdpa_flash_supported(a, false) : 0; }
+size_t mopk_sdpa_saved_bytes(const MopkSdpaArgs *a) {
+    if (!(a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0)) return 0;
+    return sdpa_use_flash(a, false) ? sdpa_flash_saved_bytes(a) : sdpa_saved_bytes(a);
+}
+size_t mopk_sdpa_workspace_bytes(const MopkSdpaArgs *a) {
+    if (!(a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0)) return 0;
+    return sdpa_use_flash(a, false) ? sdpa_flash_ws_bytes(a) : sdpa_ws_bytes(a);
+}
 int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
     if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (sdpa_use_flash(a, false)) return sdpa_flash_fwd(a, (hipStream_t)stream);
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return sdpa_fwd(a, (hipStream_t)stream);
 }
-int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream) {
+int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream) {      // the fused path also reads `y` (the forward's output)
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
-    if (!v4ok(a->q) || !v4ok(a->dy) || !v4ok(a->dq) || !v4ok(a->dk_) || !v4ok(a->dv) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !v4ok(a->dy) || !v4ok(a->dq) || !v4ok(a->dk_) || !v4ok(a->dv) ||
+        !a->saved || !a->workspace)
+        return MOPK_ERR_BAD_ARG;
+    if (sdpa_use_flash(a, false)) return sdpa_flash_bwd(a, (hipStream_t)stream);   // same decision as the forward (saved layout)
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return sdpa_bwd(a, (hipStream_t)stream);
 }

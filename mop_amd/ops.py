@@ -391,7 +391,7 @@ def _bias_f32(bias, B, H, N, dev):
 
 class _SdpaFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, bias, causal, prec):
+    def forward(ctx, q, k, v, mask, bias, causal, prec, path):
         _require_gpu(q, "SDPA")
         lib = L.lib()
         q, k, v = _heads_view(q), _heads_view(k), _heads_view(v)
@@ -399,7 +399,7 @@ class _SdpaFn(torch.autograd.Function):
         dev = q.device
         a = L.SdpaArgs()
         a.B, a.H, a.N, a.dk = B, H, N, dk
-        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(q), prec, L.PATH_GENERIC, int(bool(causal))
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(q), prec, path, int(bool(causal))
         a.q, a.k, a.v = _v4(q), _v4(k), _v4(v)
         m8, ms = _mask_u8(mask, B, H, N, dev)
         bf, bs = _bias_f32(bias, B, H, N, dev)
@@ -407,43 +407,48 @@ class _SdpaFn(torch.autograd.Function):
         a.bias, (a.bias_sb, a.bias_sh, a.bias_si) = _ptr(bf), bs
         y = torch.empty(B, N, H, dk, dtype=q.dtype, device=dev)
         a.y = _v4(y)
+        if path == L.PATH_AUTO:       # resolve once so forward, backward and the size queries agree
+            path = L.PATH_FUSED if lib.mopk_sdpa_fused_supported(C.byref(a)) else L.PATH_GENERIC
+            a.path = path
+        LAST_PATH["sdpa_fwd"] = path
         saved = _bytes(lib.mopk_sdpa_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_sdpa_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("sdpa_fwd"):
             rc = lib.mopk_sdpa_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_sdpa_fwd")
-        ctx.save_for_backward(q, k, v, saved)
-        ctx.meta = (causal, prec, m8, ms, bf, bs)
+        ctx.save_for_backward(q, k, v, y, saved)
+        ctx.meta = (causal, prec, path, m8, ms, bf, bs)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
-        q, k, v, saved = ctx.saved_tensors
-        causal, prec, m8, ms, bf, bs = ctx.meta
+        q, k, v, y, saved = ctx.saved_tensors
+        causal, prec, path, m8, ms, bf, bs = ctx.meta
         B, N, H, dk = q.shape
         dev = q.device
         dy = dy.contiguous().to(q.dtype).view(B, N, H, dk)
         a = L.SdpaArgs()
         a.B, a.H, a.N, a.dk = B, H, N, dk
-        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(q), prec, L.PATH_GENERIC, int(bool(causal))
-        a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(dy), _v4(dy)
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(q), prec, path, int(bool(causal))
+        a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(y), _v4(dy)
         a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
         a.bias, (a.bias_sb, a.bias_sh, a.bias_si) = _ptr(bf), bs
         dq, dk_, dv = (torch.empty(B, N, H, dk, dtype=q.dtype, device=dev) for _ in range(3))
         a.dq, a.dk_, a.dv = _v4(dq), _v4(dk_), _v4(dv)
+        LAST_PATH["sdpa_bwd"] = path
         ws = _bytes(lib.mopk_sdpa_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("sdpa_bwd"):
             rc = lib.mopk_sdpa_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_sdpa_bwd")
-        return dq, dk_, dv, None, None, None, None
+        return dq, dk_, dv, None, None, None, None, None
 
 
 def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False):
     """q,k,v: (B,N,H,dk) views. Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive."""
-    return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype))
+    return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype), _PATH)
 
 
 _ANCHOR_MODES = {"fixed": 0, "argmax_row_sum": 1}          # any other string -> row 0 (reference :141-145)

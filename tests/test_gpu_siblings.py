@@ -173,6 +173,44 @@ def test_whisper_self_attention_causal_bias_matches_torch():
     assert float((m(x, attn_bias=bias) - ref).detach().abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("shape", [
+    # B, N, H, dk, causal, io dtype
+    (2, 65, 6, 64, False, torch.bfloat16), (1, 197, 2, 64, False, torch.float32), (2, 300, 3, 32, True, torch.bfloat16),
+    (1, 1000, 2, 64, True, torch.bfloat16), (1, 128, 1, 64, False, torch.bfloat16), (3, 1, 2, 32, False, torch.float32),
+    (1, 129, 2, 64, True, torch.float32)])
+def test_sdpa_flash_matches_generic_and_torch(shape):
+    """fused (flash-style) SDPA kernels: forward and gradients against the generic HIP path and a plain torch fp32 reference."""
+    import mop_amd
+    from mop_amd import ops, _lib
+    B, N, H, dk, causal, dt = shape
+    mop_amd.set_precision("bf16")
+    g = torch.Generator(device="cuda").manual_seed(N)
+    qkv = torch.randn(B, N, 3, H, dk, device="cuda", generator=g)
+    dy = torch.randn(B, N, H * dk, device="cuda", generator=g)
+    res = {}
+    for path in ("fused", "generic"):
+        ops.set_path(path)
+        t = qkv.to(dt).requires_grad_(True)
+        y = ops.sdpa_core(t[:, :, 0], t[:, :, 1], t[:, :, 2], causal=causal)
+        y.backward(dy.to(dt))
+        res[path] = (y.float(), t.grad.float())
+        assert ops.LAST_PATH["sdpa_fwd"] == (_lib.PATH_FUSED if path == "fused" else _lib.PATH_GENERIC)
+    ops.set_path("auto")
+    t = qkv.to(dt).float().requires_grad_(True)                  # torch fp32 reference on the same (rounded) inputs
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    att = (q @ k.transpose(-2, -1)) / dk ** 0.5
+    if causal:
+        att = att.masked_fill(~torch.tril(torch.ones(N, N, dtype=torch.bool, device="cuda")), float("-inf"))
+    yr = (att.softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * dk)
+    yr.backward(dy.to(dt).float())
+    for path in ("fused", "generic"):
+        y, gr = res[path]
+        # north_star bf16 bound on outputs; |y| reaches ~3 here (y_0 = v_0 under the causal mask), where one bf16 ulp is 1.6e-2
+        assert float((y - yr).detach().abs().max()) <= 1e-2 * max(1.0, float(yr.detach().abs().max())), path
+        assert float((gr - t.grad).abs().max()) / float(t.grad.abs().max()) <= 3e-2, path
+    assert float((res["fused"][0] - res["generic"][0]).abs().max()) <= 1e-2 * max(1.0, float(yr.detach().abs().max()))
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)
