@@ -172,6 +172,8 @@ size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a);
 size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a);
 int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream);
 int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream);
+/* 1 if MOPK_PATH_AUTO runs this call on the fused kernels: bf16 arithmetic, dk 32/64, chain gate 0, no mask tensor (causal flag ok) */
+int mopk_dualpath_fused_supported(const MopkDualPathArgs *a);
 
 /* --------------------------------------------------------------------------
  * Quartet CausalSelfAttention core.

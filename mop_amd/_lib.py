@@ -121,6 +121,7 @@ SYMBOLS = {
     "mopk_edgewise_bwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
     "mopk_dualpath_saved_bytes": (C.c_size_t, [C.POINTER(DualPathArgs)]),
     "mopk_dualpath_workspace_bytes": (C.c_size_t, [C.POINTER(DualPathArgs)]),
+    "mopk_dualpath_fused_supported": (C.c_int, [C.POINTER(DualPathArgs)]),
     "mopk_dualpath_fwd": (C.c_int, [C.POINTER(DualPathArgs), C.c_void_p]),
     "mopk_dualpath_bwd": (C.c_int, [C.POINTER(DualPathArgs), C.c_void_p]),
     "mopk_quartet_saved_bytes": (C.c_size_t, [C.POINTER(QuartetArgs)]),

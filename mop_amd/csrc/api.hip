@@ -17,6 +17,8 @@ int sdpa_fwd(const MopkSdpaArgs *a, hipStream_t st); int sdpa_bwd(const MopkSdpa
 int sdpa_flash_supported(const MopkSdpaArgs *a, bool bwd); size_t sdpa_flash_saved_bytes(const MopkSdpaArgs *a); size_t sdpa_flash_ws_bytes(const MopkSdpaArgs *a);
 int sdpa_flash_fwd(const MopkSdpaArgs *a, hipStream_t st); int sdpa_flash_bwd(const MopkSdpaArgs *a, hipStream_t st);
 size_t dp_saved_bytes(const MopkDualPathArgs *a); size_t dp_ws_bytes(const MopkDualPathArgs *a);
+int dp_flash_supported(const MopkDualPathArgs *a, bool bwd); size_t dp_flash_saved_bytes(const MopkDualPathArgs *a); size_t dp_flash_ws_bytes(const MopkDualPathArgs *a);
+int dp_flash_fwd(const MopkDualPathArgs *a, hipStream_t st); int dp_flash_bwd(const MopkDualPathArgs *a, hipStream_t st);
 int dp_fwd(const MopkDualPathArgs *a, hipStream_t st); int dp_bwd(const MopkDualPathArgs *a, hipStream_t st);
 size_t qt_saved_bytes(const MopkQuartetArgs *a); size_t qt_ws_bytes(const MopkQuartetArgs *a);
 size_t cv_saved_bytes(const MopkCrossViewArgs *a); size_t cv_ws_bytes(const MopkCrossViewArgs *a);
@@ -162,14 +164,19 @@ static int cv_validate(const MopkCrossViewArgs *a, bool bwd) {
 }
 int mopk_crossview_fwd(const MopkCrossViewArgs *a, void *stream) { int rc = cv_validate(a, false); return rc ? rc : cv_fwd(a, (hipStream_t)stream); }
 int mopk_crossview_bwd(const MopkCrossViewArgs *a, void *stream) { int rc = cv_validate(a, true); return rc ? rc : cv_bwd(a, (hipStream_t)stream); }
-size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2) ? dp_saved_bytes(a) : 0; }
-size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a) { return (a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2) ? dp_ws_bytes(a) : 0; }
+static bool dp_ok(const MopkDualPathArgs *a) { return a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2; }
+// path: AUTO = fused kernels (sdpa_flash.hip) when the chain gate is 0 and there is no mask tensor, else generic
+static bool dp_use_flash(const MopkDualPathArgs *a) { return a->path != MOPK_PATH_GENERIC && dp_flash_supported(a, false); }
+int mopk_dualpath_fused_supported(const MopkDualPathArgs *a) { return dp_ok(a) ? dp_flash_supported(a, false) : 0; }
+size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a) { return !dp_ok(a) ? 0 : (dp_use_flash(a) ? dp_flash_saved_bytes(a) : dp_saved_bytes(a)); }
+size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a) { return !dp_ok(a) ? 0 : (dp_use_flash(a) ? dp_flash_ws_bytes(a) : dp_ws_bytes(a)); }
 int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
     if (a->hops < 2) return MOPK_ERR_BAD_SHAPE;
     if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->v2) || !v4ok(a->y) ||
         !a->chain_logit || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (dp_use_flash(a)) return dp_flash_fwd(a, (hipStream_t)stream);
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return dp_fwd(a, (hipStream_t)stream);
 }
@@ -177,8 +184,10 @@ int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
     if (a->hops < 2) return MOPK_ERR_BAD_SHAPE;
-    if (!v4ok(a->dy) || !v4ok(a->dq1) || !v4ok(a->dk1) || !v4ok(a->dv1) || !v4ok(a->dq2) || !v4ok(a->dk2) || !v4ok(a->dv2) ||
+    if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->v2) || !v4ok(a->y) ||
+        !v4ok(a->dy) || !v4ok(a->dq1) || !v4ok(a->dk1) || !v4ok(a->dv1) || !v4ok(a->dq2) || !v4ok(a->dk2) || !v4ok(a->dv2) ||
         !a->dlogit_part || !a->chain_logit || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (dp_use_flash(a)) return dp_flash_bwd(a, (hipStream_t)stream);        // same decision as the forward (saved layout)
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return dp_bwd(a, (hipStream_t)stream);
 }

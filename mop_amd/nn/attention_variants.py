@@ -38,6 +38,25 @@ _LOWRANK_PRESET = {
 _DENSE_PRESET = {"and": 0, "or": 1, "not": 2, "nor": 2, "xor": 1, "chain": 3}   # :259-272
 
 
+_CAUSAL_CACHE: Dict[Tuple[int, int, Tuple[int, ...]], bool] = {}
+
+
+def _is_causal_mask(mask: Optional[torch.Tensor], n: int) -> bool:
+    """True iff `mask` (0 = blocked) is exactly the lower-triangular causal mask shared by every batch and head.
+    The comparison runs once per mask tensor version (it synchronises)."""
+    if mask is None or mask.shape[-2:] != (n, n) or any(d != 1 for d in mask.shape[:-2]):
+        return False
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape))
+    hit = _CAUSAL_CACHE.get(key)
+    if hit is None:
+        tri = torch.ones(n, n, dtype=torch.bool, device=mask.device).tril_()
+        hit = bool(torch.equal(mask.reshape(n, n) != 0, tri))
+        if len(_CAUSAL_CACHE) > 64:
+            _CAUSAL_CACHE.clear()
+        _CAUSAL_CACHE[key] = hit
+    return hit
+
+
 class EdgewiseGateHead(nn.Module):
     """Parameters of the per-edge gate head (reference :234-309).
 
@@ -222,7 +241,8 @@ class BaselineMSA(nn.Module):
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, N, D = x.shape
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
-        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], attn_mask)
+        causal = _is_causal_mask(attn_mask, N)      # tril mask -> in-kernel causal flag (keeps the call on the fused kernels)
+        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], None if causal else attn_mask, causal=causal)
         return self.proj_drop(self.proj(y))
 
 
@@ -249,9 +269,11 @@ class MultiHopMSA(nn.Module):
         qkv1 = self.qkv1(x).view(B, N, 3, self.h, self.dk)
         qkv2 = self.qkv2(x).view(B, N, 3, self.h, self.dk)
         g = self.gates
+        causal = _is_causal_mask(attn_mask, N)      # a lower-triangular mask becomes the in-kernel causal flag (fused path)
         y = ops.dualpath_core(qkv1[:, :, 0], qkv1[:, :, 1], qkv1[:, :, 2], qkv2[:, :, 0], qkv2[:, :, 1], qkv2[:, :, 2],
                               self.chain_value_logit, g.get("and_", 1.0), g.get("or_", 0.0),
-                              g.get("not_", 0.0), g.get("chain", 0.0), self.beta_not, self.hops, attn_mask)
+                              g.get("not_", 0.0), g.get("chain", 0.0), self.beta_not, self.hops,
+                              None if causal else attn_mask, causal=causal)
         return self.proj_drop(self.proj(y))
 
 

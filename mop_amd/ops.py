@@ -525,7 +525,7 @@ def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, an
 
 class _DualPathFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q1, k1, v1, q2, k2, v2, logit, gates, beta_not, hops, mask, causal, prec):
+    def forward(ctx, q1, k1, v1, q2, k2, v2, logit, gates, beta_not, hops, mask, causal, prec, path):
         _require_gpu(q1, "MultiHopMSA")
         lib = L.lib()
         ts = [_heads_view(t) for t in (q1, k1, v1, q2, k2, v2)]
@@ -534,7 +534,7 @@ class _DualPathFn(torch.autograd.Function):
         lg = _f32c(logit).reshape(1)
         a = L.DualPathArgs()
         a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
-        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, L.PATH_GENERIC, int(bool(causal))
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, path, int(bool(causal))
         a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
         a.beta_not = float(beta_not)
         a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
@@ -543,6 +543,10 @@ class _DualPathFn(torch.autograd.Function):
         a.chain_logit = lg.data_ptr()
         y = torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev)
         a.y = _v4(y)
+        if path == L.PATH_AUTO:
+            path = L.PATH_FUSED if lib.mopk_dualpath_fused_supported(C.byref(a)) else L.PATH_GENERIC
+            a.path = path
+        LAST_PATH["dualpath_fwd"] = path
         saved = _bytes(lib.mopk_dualpath_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
@@ -550,20 +554,20 @@ class _DualPathFn(torch.autograd.Function):
             rc = lib.mopk_dualpath_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_dualpath_fwd")
         ctx.save_for_backward(*ts, lg, saved)
-        ctx.meta = (gates, beta_not, hops, causal, prec, m8, ms)
+        ctx.meta = (gates, beta_not, hops, causal, prec, path, m8, ms)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
         *ts, lg, saved = ctx.saved_tensors
-        gates, beta_not, hops, causal, prec, m8, ms = ctx.meta
+        gates, beta_not, hops, causal, prec, path, m8, ms = ctx.meta
         B, N, H, dk = ts[0].shape
         dev = ts[0].device
         dy = dy.contiguous().to(ts[0].dtype).view(B, N, H, dk)
         a = L.DualPathArgs()
         a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
-        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, L.PATH_GENERIC, int(bool(causal))
+        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, path, int(bool(causal))
         a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
         a.beta_not = float(beta_not)
         a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
@@ -579,13 +583,13 @@ class _DualPathFn(torch.autograd.Function):
         with _timed("dualpath_bwd"):
             rc = lib.mopk_dualpath_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_dualpath_bwd")
-        return (*gs, dlg.sum().reshape(()), None, None, None, None, None, None)
+        return (*gs, dlg.sum().reshape(()), None, None, None, None, None, None, None)
 
 
 def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_chain, beta_not, hops,
                   attn_mask=None, causal=False):
     return _DualPathFn.apply(q1, k1, v1, q2, k2, v2, chain_logit, (g_and, g_or, g_not, g_chain), beta_not,
-                             int(hops), attn_mask, causal, _prec_for(q1.dtype))
+                             int(hops), attn_mask, causal, _prec_for(q1.dtype), _PATH)
 
 
 class _QuartetFn(torch.autograd.Function):

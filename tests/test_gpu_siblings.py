@@ -211,6 +211,35 @@ def test_sdpa_flash_matches_generic_and_torch(shape):
     assert float((res["fused"][0] - res["generic"][0]).abs().max()) <= 1e-2 * max(1.0, float(yr.detach().abs().max()))
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, N, H, dk, hops, (and, or, not), causal, io dtype
+    (2, 197, 2, 64, 3, (1.0, 0.0, 0.0), False, torch.bfloat16), (1, 130, 3, 32, 2, (0.7, 0.4, 0.3), True, torch.bfloat16),
+    (2, 64, 2, 64, 4, (0.9, 0.5, 0.0), False, torch.float32), (1, 300, 1, 64, 3, (1.0, 0.0, 0.6), True, torch.float32)])
+def test_dualpath_fused_matches_generic(cfg):
+    """MultiHopMSA core on the fused kernels (mixed logits in one pass, transport as chained passes) vs the generic path."""
+    import mop_amd
+    from mop_amd import ops, _lib
+    B, N, H, dk, hops, (g_and, g_or, g_not), causal, dt = cfg
+    mop_amd.set_precision("bf16")
+    g = torch.Generator(device="cuda").manual_seed(N + hops)
+    base = [torch.randn(B, N, H, dk, device="cuda", generator=g) for _ in range(6)]
+    dy = torch.randn(B, N, H * dk, device="cuda", generator=g)
+    res = {}
+    for path in ("fused", "generic"):
+        ops.set_path(path)
+        ts = [t.to(dt).requires_grad_(True) for t in base]
+        lg = torch.tensor(-0.3, device="cuda", requires_grad=True)
+        y = ops.dualpath_core(*ts, lg, g_and, g_or, g_not, 0.0, 0.6, hops, causal=causal)
+        y.backward(dy.to(dt))
+        res[path] = [y.float()] + [t.grad.float() for t in ts] + [lg.grad.float()]
+        assert ops.LAST_PATH["dualpath_fwd"] == (_lib.PATH_FUSED if path == "fused" else _lib.PATH_GENERIC)
+    ops.set_path("auto")
+    names = ["y", "dq1", "dk1", "dv1", "dq2", "dk2", "dv2", "dlogit"]
+    for n_, a_, b_ in zip(names, res["fused"], res["generic"]):
+        den = max(1.0, float(b_.abs().max())) if n_ == "y" else float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) / den <= (1e-2 if n_ == "y" else 4e-2), n_
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)
