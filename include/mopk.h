@@ -204,7 +204,9 @@ typedef struct MopkQuartetArgs {
 size_t mopk_quartet_saved_bytes(const MopkQuartetArgs *a);
 size_t mopk_quartet_workspace_bytes(const MopkQuartetArgs *a);
 int mopk_quartet_fwd(const MopkQuartetArgs *a, void *stream);
-int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream);
+int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream);  /* needs q,k,v,(q2,k2), y (forward output), dy */
+/* 1 if MOPK_PATH_AUTO runs this call on the fused kernels: bf16 arithmetic, dh 32/64, no add_mask, attn == NULL */
+int mopk_quartet_fused_supported(const MopkQuartetArgs *a);
 
 /* --------------------------------------------------------------------------
  * Plain scaled-dot-product attention core.

@@ -126,6 +126,7 @@ SYMBOLS = {
     "mopk_dualpath_bwd": (C.c_int, [C.POINTER(DualPathArgs), C.c_void_p]),
     "mopk_quartet_saved_bytes": (C.c_size_t, [C.POINTER(QuartetArgs)]),
     "mopk_quartet_workspace_bytes": (C.c_size_t, [C.POINTER(QuartetArgs)]),
+    "mopk_quartet_fused_supported": (C.c_int, [C.POINTER(QuartetArgs)]),
     "mopk_quartet_fwd": (C.c_int, [C.POINTER(QuartetArgs), C.c_void_p]),
     "mopk_quartet_bwd": (C.c_int, [C.POINTER(QuartetArgs), C.c_void_p]),
     "mopk_crossview_saved_bytes": (C.c_size_t, [C.POINTER(CrossViewArgs)]),

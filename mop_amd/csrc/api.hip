@@ -21,6 +21,8 @@ int dp_flash_supported(const MopkDualPathArgs *a, bool bwd); size_t dp_flash_sav
 int dp_flash_fwd(const MopkDualPathArgs *a, hipStream_t st); int dp_flash_bwd(const MopkDualPathArgs *a, hipStream_t st);
 int dp_fwd(const MopkDualPathArgs *a, hipStream_t st); int dp_bwd(const MopkDualPathArgs *a, hipStream_t st);
 size_t qt_saved_bytes(const MopkQuartetArgs *a); size_t qt_ws_bytes(const MopkQuartetArgs *a);
+int qt_flash_supported(const MopkQuartetArgs *a, bool bwd); size_t qt_flash_saved_bytes(const MopkQuartetArgs *a); size_t qt_flash_ws_bytes(const MopkQuartetArgs *a);
+int qt_flash_fwd(const MopkQuartetArgs *a, hipStream_t st); int qt_flash_bwd(const MopkQuartetArgs *a, hipStream_t st);
 size_t cv_saved_bytes(const MopkCrossViewArgs *a); size_t cv_ws_bytes(const MopkCrossViewArgs *a);
 int cv_fwd(const MopkCrossViewArgs *a, hipStream_t st); int cv_bwd(const MopkCrossViewArgs *a, hipStream_t st);
 int qt_fwd(const MopkQuartetArgs *a, hipStream_t st); int qt_bwd(const MopkQuartetArgs *a, hipStream_t st);
@@ -191,21 +193,29 @@ int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream) {
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return dp_bwd(a, (hipStream_t)stream);
 }
-size_t mopk_quartet_saved_bytes(const MopkQuartetArgs *a) { return (a && a->B > 0 && a->H > 0 && a->T > 0 && a->dh > 0) ? qt_saved_bytes(a) : 0; }
-size_t mopk_quartet_workspace_bytes(const MopkQuartetArgs *a) { return (a && a->B > 0 && a->H > 0 && a->T > 0 && a->dh > 0) ? qt_ws_bytes(a) : 0; }
+static bool qt_ok(const MopkQuartetArgs *a) { return a && a->B > 0 && a->H > 0 && a->T > 0 && a->dh > 0; }
+// path: AUTO = fused kernels (quartet_flash.hip) without an additive mask / returned attention weights, else generic
+static bool qt_use_flash(const MopkQuartetArgs *a) { return a->path != MOPK_PATH_GENERIC && qt_flash_supported(a, false); }
+int mopk_quartet_fused_supported(const MopkQuartetArgs *a) { return qt_ok(a) ? qt_flash_supported(a, false) : 0; }
+size_t mopk_quartet_saved_bytes(const MopkQuartetArgs *a) { return !qt_ok(a) ? 0 : (qt_use_flash(a) ? qt_flash_saved_bytes(a) : qt_saved_bytes(a)); }
+size_t mopk_quartet_workspace_bytes(const MopkQuartetArgs *a) { return !qt_ok(a) ? 0 : (qt_use_flash(a) ? qt_flash_ws_bytes(a) : qt_ws_bytes(a)); }
 int mopk_quartet_fwd(const MopkQuartetArgs *a, void *stream) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->T, a->dh, a->io_dtype, a->precision); if (rc) return rc;
     if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
     if (a->use_quartet && (!v4ok(a->q2) || !v4ok(a->k2) || !a->mixture || !a->quartet_scale)) return MOPK_ERR_BAD_ARG;
+    if (qt_use_flash(a)) return qt_flash_fwd(a, (hipStream_t)stream);
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return qt_fwd(a, (hipStream_t)stream);
 }
-int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream) {
+int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream) {    // the fused path also reads `y` (the forward's output)
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->T, a->dh, a->io_dtype, a->precision); if (rc) return rc;
-    if (!v4ok(a->dy) || !v4ok(a->dq) || !v4ok(a->dk_) || !v4ok(a->dv) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
-    if (a->use_quartet && (!v4ok(a->dq2) || !v4ok(a->dk2) || !a->dmixture_part || !a->dqscale_part || !a->mixture || !a->quartet_scale)) return MOPK_ERR_BAD_ARG;
+    if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !v4ok(a->dy) || !v4ok(a->dq) || !v4ok(a->dk_) || !v4ok(a->dv) ||
+        !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->use_quartet && (!v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->dq2) || !v4ok(a->dk2) || !a->dmixture_part || !a->dqscale_part ||
+                           !a->mixture || !a->quartet_scale)) return MOPK_ERR_BAD_ARG;
+    if (qt_use_flash(a)) return qt_flash_bwd(a, (hipStream_t)stream);
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return qt_bwd(a, (hipStream_t)stream);
 }

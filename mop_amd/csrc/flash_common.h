@@ -1,0 +1,82 @@
+// Shared device helpers of the fused (flash-style) attention kernels: sdpa_flash.hip, quartet_flash.hip.
+#pragma once
+#include "fused_common.h"
+
+namespace mopk {
+namespace {   // internal linkage: each translation unit gets its own copies
+constexpr int FA_NW = 4, FA_QB = 32 * FA_NW, FA_KT = 64, FA_LDT = FA_KT + 8;
+constexpr float FA_NEG = -1e30f, FA_LOG2E = 1.4426950408889634f, FA_LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ f32x16 fa_zero() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ void fa_pack(bf16x8 &lo, bf16x8 &hi, const f32x16 &x) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { lo[j] = (short)f2bf(x[j]); hi[j] = (short)f2bf(x[8 + j]); }
+}
+// row fragments of one token: 8 contiguous features at 16 s + 8 h, optionally scaled (rounded to bf16 once)
+template <int DK, typename IOT>
+__device__ __forceinline__ void fa_frags(bf16x8 (&f)[DK / 16], const IOT *row, bool ok, int h, float scale) {
+#pragma unroll
+    for (int s = 0; s < DK / 16; ++s) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok) v = load8_bf16<IOT>(row + 16 * s + 8 * h);
+        if (scale != 1.f) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(bf2f((unsigned short)v[j]) * scale);
+        }
+        f[s] = v;
+    }
+}
+// stage a tile of TK tokens: row-major image rows[tok][DK+8] and/or transposed image cols[d][perm(tok)]
+template <int DK, typename IOT, bool ROWS, bool COLS>
+__device__ __forceinline__ void fa_stage(unsigned short *rows, unsigned short *cols, const IOT *base, int64_t sn, int t0, int N,
+                                         float scale, int tid) {
+    constexpr int CH = DK / 8, LDK = DK + 8;
+    for (int c = tid; c < FA_KT * CH; c += FA_NW * 64) {
+        const int j = c / CH, dc = c % CH;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + j < N) v = load8_bf16<IOT>(base + (int64_t)(t0 + j) * sn + dc * 8);
+        if (scale != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((unsigned short)v[e]) * scale);
+        }
+        if (ROWS) *(bf16x8 *)&rows[j * LDK + dc * 8] = v;
+        if (COLS) {
+            const int col = (j & ~15) + kperm16(j & 15);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cols[(dc * 8 + e) * FA_LDT + col] = (unsigned short)v[e];
+        }
+    }
+}
+// 32x32 tile: sum_s A[(row0 + r)][16 s + 8 h ..] x B[s]   (A from a row-major LDS image with stride DK+8)
+template <int DK>
+__device__ __forceinline__ f32x16 fa_mm_rows(const unsigned short *img, int row0, int r, int h, const bf16x8 (&B)[DK / 16]) {
+    f32x16 acc = fa_zero();
+#pragma unroll
+    for (int s = 0; s < DK / 16; ++s) {
+        const bf16x8 af = *(const bf16x8 *)&img[(row0 + r) * (DK + 8) + 16 * s + 8 * h];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, B[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+// acc[dt] += T[d = 32 dt + r][32 half + ..] x packed tile (lo: k 0-15, hi: k 16-31 of this 32-token half)
+template <int DK>
+__device__ __forceinline__ void fa_mm_cols(f32x16 (&acc)[DK / 32], const unsigned short *timg, int half, int r, int h, bf16x8 lo, bf16x8 hi) {
+#pragma unroll
+    for (int dt = 0; dt < DK / 32; ++dt) {
+        const unsigned short *p = &timg[(32 * dt + r) * FA_LDT + 32 * half + 8 * h];
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)p, lo, acc[dt], 0, 0, 0);
+        acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8 *)(p + 16), hi, acc[dt], 0, 0, 0);
+    }
+}
+// write a transposed accumulator (lane = token, registers = features) to a (.., token, feature) tensor row
+template <int DK, typename IOT>
+__device__ __forceinline__ void fa_store_rows(IOT *row, const f32x16 (&acc)[DK / 32], int h, float scale) {
+#pragma unroll
+    for (int dt = 0; dt < DK / 32; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+            store4<IOT>(row + 32 * dt + 8 * g4 + 4 * h, acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale, acc[dt][4 * g4 + 2] * scale,
+                        acc[dt][4 * g4 + 3] * scale);
+}
+}  // namespace
+}  // namespace mopk

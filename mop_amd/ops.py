@@ -594,7 +594,7 @@ def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_cha
 
 class _QuartetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, q2, k2, mixture, qscale, add_mask, eps, use_quartet, need_weights, prec):
+    def forward(ctx, q, k, v, q2, k2, mixture, qscale, add_mask, eps, use_quartet, need_weights, prec, path):
         _require_gpu(q, "CausalSelfAttention")
         lib = L.lib()
         ts = [_heads_view(t) for t in ((q, k, v, q2, k2) if use_quartet else (q, k, v))]
@@ -602,7 +602,7 @@ class _QuartetFn(torch.autograd.Function):
         dev = ts[0].device
         a = L.QuartetArgs()
         a.B, a.H, a.T, a.dh = B, H, T, dh
-        a.io_dtype, a.precision, a.path = _io_dtype(ts[0]), prec, L.PATH_GENERIC
+        a.io_dtype, a.precision, a.path = _io_dtype(ts[0]), prec, path
         a.use_quartet, a.eps = int(bool(use_quartet)), float(eps)
         a.q, a.k, a.v = _v4(ts[0]), _v4(ts[1]), _v4(ts[2])
         sc = []
@@ -616,14 +616,18 @@ class _QuartetFn(torch.autograd.Function):
         a.y = _v4(y)
         attn = torch.empty(B, H, T, T, dtype=torch.float32, device=dev) if need_weights else None
         a.attn = _ptr(attn)
+        if path == L.PATH_AUTO:
+            path = L.PATH_FUSED if lib.mopk_quartet_fused_supported(C.byref(a)) else L.PATH_GENERIC
+            a.path = path
+        LAST_PATH["quartet_fwd"] = path
         saved = _bytes(lib.mopk_quartet_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_quartet_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("quartet_fwd"):
             rc = lib.mopk_quartet_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_quartet_fwd")
-        ctx.save_for_backward(*ts, *sc, saved)
-        ctx.meta = (eps, use_quartet, prec, am, ams)
+        ctx.save_for_backward(*ts, *sc, y, saved)
+        ctx.meta = (eps, use_quartet, prec, path, am, ams)
         out = y.view(B, T, H * dh)
         if need_weights:
             ctx.mark_non_differentiable(attn)
@@ -633,19 +637,19 @@ class _QuartetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         lib = L.lib()
-        eps, use_quartet, prec, am, ams = ctx.meta
+        eps, use_quartet, prec, path, am, ams = ctx.meta
         if use_quartet:
-            q, k, v, q2, k2, mix, qs, saved = ctx.saved_tensors
+            q, k, v, q2, k2, mix, qs, y, saved = ctx.saved_tensors
         else:
-            q, k, v, saved = ctx.saved_tensors
+            q, k, v, y, saved = ctx.saved_tensors
         B, T, H, dh = q.shape
         dev = q.device
         dy = dy.contiguous().to(q.dtype).view(B, T, H, dh)
         a = L.QuartetArgs()
         a.B, a.H, a.T, a.dh = B, H, T, dh
-        a.io_dtype, a.precision, a.path = _io_dtype(q), prec, L.PATH_GENERIC
+        a.io_dtype, a.precision, a.path = _io_dtype(q), prec, path
         a.use_quartet, a.eps = int(bool(use_quartet)), float(eps)
-        a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(dy), _v4(dy)
+        a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(y), _v4(dy)
         a.add_mask, (a.am_sb, a.am_sh, a.am_si) = _ptr(am), ams
         n = 5 if use_quartet else 3
         gs = [torch.empty(B, T, H, dh, dtype=q.dtype, device=dev) for _ in range(n)]
@@ -664,10 +668,10 @@ class _QuartetFn(torch.autograd.Function):
         L.check(rc, "mopk_quartet_bwd")
         if use_quartet:
             return (gs[0], gs[1], gs[2], gs[3], gs[4], dmix.sum().reshape(1), dqs.sum().reshape(1),
-                    None, None, None, None, None)
-        return (gs[0], gs[1], gs[2], None, None, None, None, None, None, None, None, None)
+                    None, None, None, None, None, None)
+        return (gs[0], gs[1], gs[2], None, None, None, None, None, None, None, None, None, None)
 
 
 def quartet_core(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights=False):
     return _QuartetFn.apply(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights,
-                            _prec_for(q.dtype))
+                            _prec_for(q.dtype), _PATH)

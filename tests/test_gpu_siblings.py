@@ -240,6 +240,38 @@ def test_dualpath_fused_matches_generic(cfg):
         assert float((a_ - b_).abs().max()) / den <= (1e-2 if n_ == "y" else 4e-2), n_
 
 
+@pytest.mark.parametrize("cfg", [
+    # B, T, H, dh, use_quartet, io dtype
+    (2, 64, 2, 64, True, torch.bfloat16), (1, 200, 3, 32, True, torch.float32), (2, 130, 2, 64, False, torch.bfloat16),
+    (1, 513, 2, 64, True, torch.bfloat16), (1, 1, 2, 32, True, torch.float32)])
+def test_quartet_fused_matches_generic(cfg):
+    """Quartet core on the fused kernels (row statistics pass + online-softmax pass; dense z-norm corrections in the backward)."""
+    import mop_amd
+    from mop_amd import ops, _lib
+    B, T, H, dh, uq, dt = cfg
+    mop_amd.set_precision("bf16")
+    g = torch.Generator(device="cuda").manual_seed(T)
+    base = [torch.randn(B, T, H, dh, device="cuda", generator=g) for _ in range(5)]
+    dy = torch.randn(B, T, H * dh, device="cuda", generator=g)
+    res = {}
+    for path in ("fused", "generic"):
+        ops.set_path(path)
+        ts = [t.to(dt).requires_grad_(True) for t in base]
+        mix = torch.tensor([0.3], device="cuda", requires_grad=True)
+        qs = torch.tensor([0.8], device="cuda", requires_grad=True)
+        y = ops.quartet_core(ts[0], ts[1], ts[2], ts[3] if uq else None, ts[4] if uq else None, mix if uq else None, qs if uq else None,
+                             None, 1e-5, uq)
+        y.backward(dy.to(dt))
+        n = 5 if uq else 3
+        res[path] = [y.float()] + [t.grad.float() for t in ts[:n]] + ([mix.grad.float(), qs.grad.float()] if uq else [])
+        assert ops.LAST_PATH["quartet_fwd"] == (_lib.PATH_FUSED if path == "fused" else _lib.PATH_GENERIC)
+    ops.set_path("auto")
+    names = ["y", "dq", "dk", "dv", "dq2", "dk2", "dmixture", "dquartet_scale"]
+    for n_, a_, b_ in zip(names, res["fused"], res["generic"]):
+        den = max(1.0, float(b_.abs().max())) if n_ == "y" else max(float(b_.abs().max()), 1e-6)
+        assert float((a_ - b_).abs().max()) / den <= (1e-2 if n_ == "y" else 5e-2), n_
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)
