@@ -292,3 +292,56 @@ def test_vit_mop_shapes_and_gate_api():
         assert m(x).shape == (2, 10)
     gates, views, kernels = m.get_gate_maps(x)
     assert gates.ndim == 4 and gates.shape[1] == 1 and views.shape[1] == 2 and kernels.shape[1] == 1
+
+
+# ---- BASELINE.json config sizes: size-independent properties of the fused sibling kernels (no oracle at these sizes)
+def test_sdpa_whisper_size_key_permutation_and_value_linearity():
+    """T=3000, d=384, H=6 (config 5): non-causal attention is invariant to a joint permutation of keys/values and linear in v."""
+    from mop_amd import ops
+    torch.manual_seed(0)
+    B, T, H, dk = 2, 3000, 6, 64
+    q, k, v, v2 = (torch.randn(B, T, H, dk, device="cuda", dtype=torch.bfloat16) for _ in range(4))
+    with torch.no_grad():
+        y = ops.sdpa_core(q, k, v).float()
+        perm = torch.randperm(T, device="cuda")
+        yp = ops.sdpa_core(q, k[:, perm].contiguous(), v[:, perm].contiguous()).float()
+        ys = ops.sdpa_core(q, k, (v.float() + 2 * v2.float()).to(torch.bfloat16)).float()
+        y2 = ops.sdpa_core(q, k, v2).float()
+    assert float((y - yp).abs().max()) <= 2e-2                     # summation order changes with the tiling of the permuted keys
+    assert float((ys - (y + 2 * y2)).abs().max()) <= 6e-2          # bf16 rounding of v + 2 v2 and of three outputs
+    assert torch.isfinite(y).all()
+
+
+def test_quartet_gpt_size_first_row_and_value_linearity():
+    """T=1024, d=768, H=12 (config 4): row 0 sees only key 0 (y_0 = v_0); the output is linear in v; gradients are finite."""
+    from mop_amd import ops
+    torch.manual_seed(1)
+    B, T, H, dh = 2, 1024, 12, 64
+    q, k, v, q2, k2, v2 = (torch.randn(B, T, H, dh, device="cuda", dtype=torch.bfloat16) for _ in range(6))
+    mix, qs = torch.tensor([0.2], device="cuda"), torch.tensor([0.9], device="cuda")
+    with torch.no_grad():
+        y = ops.quartet_core(q, k, v, q2, k2, mix, qs, None, 1e-5, True).float().view(B, T, H, dh)
+        yb = ops.quartet_core(q, k, v2, q2, k2, mix, qs, None, 1e-5, True).float().view(B, T, H, dh)
+        ys = ops.quartet_core(q, k, (v.float() - v2.float()).to(torch.bfloat16), q2, k2, mix, qs, None, 1e-5, True).float().view(B, T, H, dh)
+    assert float((y[:, 0] - v[:, 0].float()).abs().max()) <= 2e-2
+    assert float((ys - (y - yb)).abs().max()) <= 6e-2
+    qg = q.clone().requires_grad_(True)
+    ops.quartet_core(qg, k, v, q2, k2, mix, qs, None, 1e-5, True).sum().backward()
+    assert torch.isfinite(qg.grad).all() and float(qg.grad.abs().max()) > 0
+
+
+def test_multihop_full_size_is_deterministic():
+    """N=197, d=384, H=6, B=32: two runs of the fused dual-path forward+backward are bit-identical (no atomics anywhere)."""
+    from mop_amd.nn import MultiHopMSA
+    torch.manual_seed(2)
+    m = MultiHopMSA(384, 6).cuda().to(torch.bfloat16)
+    x = torch.randn(32, 197, 384, device="cuda", dtype=torch.bfloat16)
+    outs = []
+    for _ in range(2):
+        xg = x.clone().requires_grad_(True)
+        m.zero_grad()
+        y = m(xg)
+        y.float().square().sum().backward()
+        outs.append((y.detach().clone(), xg.grad.clone(), m.qkv2.weight.grad.clone()))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
