@@ -152,7 +152,8 @@ int mopk_edgewise_bwd(const MopkEdgewiseArgs *a, void *stream);
  * -------------------------------------------------------------------------- */
 typedef struct MopkDualPathArgs {
     int32_t B, H, N, dk;
-    int32_t hops;            /* >= 2  :174 */
+    int32_t hops;            /* >= 2  :174 ; 0 = no value-transport term (two-score attention only; fused kernels only,
+                              * v2 / dv2 / chain_logit unused) -- CrossViewMixerMSA's 2x2 mix folds into (k1', k2') */
     int32_t io_dtype, precision, path;
     int32_t causal;
     float g_and, g_or, g_not, g_chain; /* python-float gates :188 */

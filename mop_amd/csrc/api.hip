@@ -166,7 +166,7 @@ static int cv_validate(const MopkCrossViewArgs *a, bool bwd) {
 }
 int mopk_crossview_fwd(const MopkCrossViewArgs *a, void *stream) { int rc = cv_validate(a, false); return rc ? rc : cv_fwd(a, (hipStream_t)stream); }
 int mopk_crossview_bwd(const MopkCrossViewArgs *a, void *stream) { int rc = cv_validate(a, true); return rc ? rc : cv_bwd(a, (hipStream_t)stream); }
-static bool dp_ok(const MopkDualPathArgs *a) { return a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && a->hops >= 2; }
+static bool dp_ok(const MopkDualPathArgs *a) { return a && a->B > 0 && a->H > 0 && a->N > 0 && a->dk > 0 && (a->hops >= 2 || a->hops == 0); }
 // path: AUTO = fused kernels (sdpa_flash.hip) when the chain gate is 0 and there is no mask tensor, else generic
 static bool dp_use_flash(const MopkDualPathArgs *a) { return a->path != MOPK_PATH_GENERIC && dp_flash_supported(a, false); }
 int mopk_dualpath_fused_supported(const MopkDualPathArgs *a) { return dp_ok(a) ? dp_flash_supported(a, false) : 0; }
@@ -175,22 +175,24 @@ size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a) { return !dp_ok(
 int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
-    if (a->hops < 2) return MOPK_ERR_BAD_SHAPE;
-    if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->v2) || !v4ok(a->y) ||
-        !a->chain_logit || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->hops < 2 && a->hops != 0) return MOPK_ERR_BAD_SHAPE;
+    if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->y) || !a->saved || !a->workspace)
+        return MOPK_ERR_BAD_ARG;
+    if (a->hops > 0 && (!v4ok(a->v2) || !a->chain_logit)) return MOPK_ERR_BAD_ARG;
     if (dp_use_flash(a)) return dp_flash_fwd(a, (hipStream_t)stream);
-    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    if (a->path == MOPK_PATH_FUSED || a->hops == 0) return MOPK_ERR_UNSUPPORTED;     // hops == 0 exists on the fused kernels only
     return dp_fwd(a, (hipStream_t)stream);
 }
 int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
-    if (a->hops < 2) return MOPK_ERR_BAD_SHAPE;
-    if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->v2) || !v4ok(a->y) ||
-        !v4ok(a->dy) || !v4ok(a->dq1) || !v4ok(a->dk1) || !v4ok(a->dv1) || !v4ok(a->dq2) || !v4ok(a->dk2) || !v4ok(a->dv2) ||
-        !a->dlogit_part || !a->chain_logit || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->hops < 2 && a->hops != 0) return MOPK_ERR_BAD_SHAPE;
+    if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->y) ||
+        !v4ok(a->dy) || !v4ok(a->dq1) || !v4ok(a->dk1) || !v4ok(a->dv1) || !v4ok(a->dq2) || !v4ok(a->dk2) ||
+        !a->dlogit_part || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->hops > 0 && (!v4ok(a->v2) || !v4ok(a->dv2) || !a->chain_logit)) return MOPK_ERR_BAD_ARG;
     if (dp_use_flash(a)) return dp_flash_bwd(a, (hipStream_t)stream);        // same decision as the forward (saved layout)
-    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    if (a->path == MOPK_PATH_FUSED || a->hops == 0) return MOPK_ERR_UNSUPPORTED;
     return dp_bwd(a, (hipStream_t)stream);
 }
 static bool qt_ok(const MopkQuartetArgs *a) { return a && a->B > 0 && a->H > 0 && a->T > 0 && a->dh > 0; }

@@ -331,7 +331,7 @@ static DpLayout dp_saved(void *p, const MopkDualPathArgs *a) {
     const size_t rows = (size_t)a->B * a->H * a->N, nd = rows * a->dk, es = a->io_dtype == MOPK_BF16 ? 2 : 4;
     DpLayout L;
     L.lse_m = c.take<float>(rows); L.lse_1 = c.take<float>(rows); L.lse_2 = c.take<float>(rows);
-    L.O1 = c.take<char>(nd * es); L.yc = c.take<char>(nd * es); L.tr = c.take<char>((size_t)(a->hops - 1) * ((nd * es + 255) & ~(size_t)255));
+    L.O1 = c.take<char>(nd * es); L.yc = c.take<char>(nd * es); L.tr = c.take<char>((size_t)(a->hops > 1 ? a->hops - 1 : 0) * ((nd * es + 255) & ~(size_t)255));
     L.bytes = c.off;
     return L;
 }
@@ -402,8 +402,9 @@ int dp_flash_supported(const MopkDualPathArgs *a, bool bwd) {
     s.q = a->q1; s.k = a->k1; s.v = a->v1; s.y = a->y;
     if (bwd) { s.dy = a->dy; s.dq = a->dq1; s.dk_ = a->dk1; s.dv = a->dv1; }
     if (a->precision != MOPK_PREC_BF16 || !sdpa_flash_supported(&s, bwd)) return 0;
-    s.q = a->q2; s.k = a->k2; s.v = a->v2;
-    if (bwd) { s.dq = a->dq2; s.dk_ = a->dk2; s.dv = a->dv2; }
+    s.q = a->q2; s.k = a->k2;
+    if (bwd) { s.dq = a->dq2; s.dk_ = a->dk2; }
+    if (a->hops > 0) { s.v = a->v2; if (bwd) s.dv = a->dv2; }      // hops == 0: no transport term, v2 / dv2 are not touched
     return sdpa_flash_supported(&s, bwd);
 }
 size_t dp_flash_saved_bytes(const MopkDualPathArgs *a) { return dp_saved(nullptr, a).bytes + 256; }
@@ -438,7 +439,7 @@ int dp_flash_fwd(const MopkDualPathArgs *a, hipStream_t st) {
     if (!dp_flash_supported(a, false)) return MOPK_ERR_UNSUPPORTED;
     const DpLayout L = dp_saved(a->saved, a);
     const size_t es = a->io_dtype == MOPK_BF16 ? 2 : 4, trs = ((size_t)a->B * a->H * a->N * a->dk * es + 255) & ~(size_t)255;
-    const MopkView4 o1 = dp_tmp_view(L.O1, a), yc = dp_tmp_view(L.yc, a);
+    const MopkView4 o1 = a->hops > 0 ? dp_tmp_view(L.O1, a) : a->y, yc = dp_tmp_view(L.yc, a);
     {   // mixed logits: S1 + a2 S2 + g_or (lse - S1)                                           :209-213, :219-221
         MopkSdpaArgs s = dp_sdpa(a);
         s.q = a->q1; s.k = a->k1; s.v = a->v1; s.y = o1;
@@ -448,6 +449,7 @@ int dp_flash_fwd(const MopkDualPathArgs *a, hipStream_t st) {
         { const MopkSdpaArgs *a = keep; FA_DISPATCH(sdpa_flash_fwd_kernel, true, grid, *a, L.lse_m, u); }
         MOPK_CHECK_LAUNCH();
     }
+    if (a->hops == 0) return MOPK_OK;                              // two-score attention only (CrossViewMixerMSA's fused path)
     MopkView4 t = a->v2;                                           // value transport A1 A2^(hops-1) v2   :224-227
     for (int i = 1; i < a->hops; ++i) {
         const MopkView4 nt = dp_tmp_view((char *)L.tr + (size_t)(i - 1) * trs, a);
@@ -465,12 +467,13 @@ int dp_flash_bwd(const MopkDualPathArgs *a, hipStream_t st) {
     const DpLayout L = dp_saved(a->saved, a);
     const DpWork W = dp_work(a->workspace, a);
     const size_t es = a->io_dtype == MOPK_BF16 ? 2 : 4, trs = ((size_t)a->B * a->H * a->N * a->dk * es + 255) & ~(size_t)255;
-    const MopkView4 o1 = dp_tmp_view(L.O1, a), yc = dp_tmp_view(L.yc, a), g = dp_tmp_view(W.g, a), tq = dp_tmp_view(W.tq, a),
-                    tk = dp_tmp_view(W.tk, a);
+    const MopkView4 o1 = a->hops > 0 ? dp_tmp_view(L.O1, a) : a->y, yc = dp_tmp_view(L.yc, a), g = dp_tmp_view(W.g, a),
+                    tq = dp_tmp_view(W.tq, a), tk = dp_tmp_view(W.tk, a);
     auto tr = [&](int i) { return i == 0 ? a->v2 : dp_tmp_view((char *)L.tr + (size_t)(i - 1) * trs, a); };
-    if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((dp_dlogit_kernel<unsigned short>), dim3(a->B * a->H), dim3(256), 0, st, a->dy, yc, a->chain_logit, a->dlogit_part, a->H, a->N, a->dk);
+    if (a->hops == 0) hipMemsetAsync(a->dlogit_part, 0, sizeof(float) * a->B * a->H, st);
+    else if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((dp_dlogit_kernel<unsigned short>), dim3(a->B * a->H), dim3(256), 0, st, a->dy, yc, a->chain_logit, a->dlogit_part, a->H, a->N, a->dk);
     else hipLaunchKernelGGL((dp_dlogit_kernel<float>), dim3(a->B * a->H), dim3(256), 0, st, a->dy, yc, a->chain_logit, a->dlogit_part, a->H, a->N, a->dk);
-    DP_ELEM(dp_scale_kernel, g, a->dy, a->chain_logit);            // gradient reaching the transport term
+    if (a->hops > 0) DP_ELEM(dp_scale_kernel, g, a->dy, a->chain_logit);   // gradient reaching the transport term
     MOPK_CHECK_LAUNCH();
     {   // mixed-logit pass: dq1, dk1, dv1, dq2, dk2 straight into the caller's tensors
         MopkSdpaArgs s = dp_sdpa(a);
@@ -485,6 +488,7 @@ int dp_flash_bwd(const MopkDualPathArgs *a, hipStream_t st) {
           FA_DISPATCH(sdpa_flash_dkv_kernel, true, grid, *a, (const float *)L.lse_m, (const float *)W.delta, u); }
         MOPK_CHECK_LAUNCH();
     }
+    if (a->hops == 0) return MOPK_OK;
     // transport term backwards: yc = A1 t_{h-1}, t_i = A2 t_{i-1}, t_0 = v2
     const int hm = a->hops - 1;
     MopkView4 cur = hm >= 1 ? dp_tmp_view(W.ta, a) : a->dv2;       // gradient wrt t_{h-1}

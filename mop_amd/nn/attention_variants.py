@@ -305,9 +305,11 @@ class CrossViewMixerMSA(nn.Module):
         b = self.qkv2(x).view(B, N, 3, self.h, self.dk)           # v2 is unused by the reference too (:98)
         cues = self.use_transpose_cues
         pw = self.prior_weight if (self.enable_per_key_prior and self.prior_weight > 0.0) else 0.0     # :126
+        causal = _is_causal_mask(attn_mask, N)
         y = ops.crossview_core(a[:, :, 0], a[:, :, 1], a[:, :, 2], b[:, :, 0], b[:, :, 1], self.mix,
                                t1=self.t1 if cues else 0.0, t2=self.t2 if cues else 0.0, prior_weight=pw,
-                               anchor_mode=self.anchor_mode, fixed_k_star=self.fixed_k_star, attn_mask=attn_mask)
+                               anchor_mode=self.anchor_mode, fixed_k_star=self.fixed_k_star,
+                               attn_mask=None if causal else attn_mask, causal=causal)
         return self.proj_drop(self.proj(y))
 
 

@@ -519,8 +519,20 @@ class _CrossViewFn(torch.autograd.Function):
 def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, anchor_mode="argmax_row_sum", fixed_k_star=0,
                    attn_mask=None, causal=False):
     """q*,k*,v1: (B,N,H,dk) views; mix (2,2).  prior_weight = 0 disables the per-key prior.  Returns (B,N,H*dk)."""
+    prec = _prec_for(q1.dtype)
+    if (prior_weight <= 0.0 and t1 == 0.0 and t2 == 0.0 and attn_mask is None and _PATH != L.PATH_GENERIC and prec == L.PREC_BF16
+            and q1.shape[-1] in (32, 64)):
+        # S = q1 (m11 k1 + m12 k2)^T + q2 (m21 k1 + m22 k2)^T: the 2x2 mix folds into two mixed key tensors (autograd carries
+        # d mix, d k1, d k2) and the core is the fused two-score attention (dual-path kernels without the transport term)
+        m = mix.to(k1.dtype)
+        k1p = (m[0, 0] * k1 + m[0, 1] * k2).contiguous()
+        k2p = (m[1, 0] * k1 + m[1, 1] * k2).contiguous()
+        zero = q1.new_zeros((), dtype=torch.float32)
+        LAST_PATH["crossview_fwd"] = L.PATH_FUSED
+        return _DualPathFn.apply(q1, k1p, v1, q2, k2p, v1, zero, (1.0, 0.0, 0.0, 0.0), 0.0, 0, None, causal, prec, L.PATH_FUSED)
+    LAST_PATH["crossview_fwd"] = L.PATH_GENERIC
     cfg = (float(t1), float(t2), float(prior_weight), int(prior_weight > 0.0), _ANCHOR_MODES.get(anchor_mode, 2), int(fixed_k_star))
-    return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, _prec_for(q1.dtype))
+    return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, prec)
 
 
 class _DualPathFn(torch.autograd.Function):
@@ -553,14 +565,14 @@ class _DualPathFn(torch.autograd.Function):
         with _timed("dualpath_fwd"):
             rc = lib.mopk_dualpath_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_dualpath_fwd")
-        ctx.save_for_backward(*ts, lg, saved)
+        ctx.save_for_backward(*ts, lg, y, saved)
         ctx.meta = (gates, beta_not, hops, causal, prec, path, m8, ms)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
-        *ts, lg, saved = ctx.saved_tensors
+        *ts, lg, y, saved = ctx.saved_tensors
         gates, beta_not, hops, causal, prec, path, m8, ms = ctx.meta
         B, N, H, dk = ts[0].shape
         dev = ts[0].device
@@ -573,8 +585,9 @@ class _DualPathFn(torch.autograd.Function):
         a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
         a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
         a.chain_logit = lg.data_ptr()
-        a.y, a.dy = _v4(dy), _v4(dy)
-        gs = [torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(6)]
+        a.y, a.dy = _v4(y), _v4(dy)
+        mk = torch.zeros if hops == 0 else torch.empty          # hops == 0: dv2 is never written
+        gs = [mk(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(6)]
         a.dq1, a.dk1, a.dv1, a.dq2, a.dk2, a.dv2 = (_v4(g) for g in gs)
         dlg = torch.empty(B, H, dtype=torch.float32, device=dev)
         a.dlogit_part = dlg.data_ptr()

@@ -272,6 +272,33 @@ def test_quartet_fused_matches_generic(cfg):
         assert float((a_ - b_).abs().max()) / den <= (1e-2 if n_ == "y" else 5e-2), n_
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_crossview_fused_default_matches_generic(causal):
+    """CrossViewMixerMSA without cues / prior: the 2x2 mix folds into two mixed key tensors + the fused two-score kernels."""
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import CrossViewMixerMSA
+    mop_amd.set_precision("bf16")
+    torch.manual_seed(5)
+    m = CrossViewMixerMSA(128, 2).cuda()
+    with torch.no_grad():
+        m.mix.add_(0.3 * torch.randn(2, 2, device="cuda"))
+    x = torch.randn(2, 150, 128, device="cuda")
+    mask = torch.tril(torch.ones(150, 150, device="cuda")).view(1, 1, 150, 150) if causal else None
+    res = {}
+    for path in ("auto", "generic"):
+        ops.set_path(path)
+        m.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        y = m(xg, attn_mask=mask)
+        y.square().sum().backward()
+        res[path] = [y.detach(), xg.grad, m.mix.grad.clone(), m.qkv2.weight.grad.clone()]
+        assert ops.LAST_PATH["crossview_fwd"] == (_lib.PATH_FUSED if path == "auto" else _lib.PATH_GENERIC)
+    ops.set_path("auto")
+    for a_, b_ in zip(res["auto"], res["generic"]):
+        assert float((a_ - b_).abs().max()) / max(float(b_.abs().max()), 1e-6) <= 4e-2
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)
