@@ -404,35 +404,36 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ---------------- gate vectors                                     :323-326
     const int C = 2 * V + 2;
-    if (tid < NP) {                       // b[g,k,j] -> bT[g][j][slots] = [b_hi | b_hi | b_lo | 0]
-        const int j = tid;
-        for (int g = 0; g < 4; ++g) {
-            unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
-            if (j < N)
-                for (int k = 0; k < R; ++k) {
-                    const int o = g * R + k;
-                    float s = a.bc[o];
-                    for (int c = 0; c < C; ++c) {
-                        const float f = c < V ? cS[c * NP + j] : (c < 2 * V ? rS[(c - V) * NP + j] : (c == 2 * V ? cCr[j] : cCl[j]));
-                        s = fmaf(a.Wc[o * C + c], f, s);
-                    }
-                    hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
-                }
-            unsigned short *row = bT + (g * NP + j) * BTS;
+    float *Wsm = Cfg::WSM_EXTRA ? wsig + 8 : colpart;   // [2][16][19] gate-head weights (+bias in slot 18); colpart is dead from here on
+    for (int c = tid; c < 2 * 4 * R * (C + 1); c += NT * 64) {
+        const int side = c / (4 * R * (C + 1)), rem = c % (4 * R * (C + 1)), o = rem / (C + 1), cc = rem % (C + 1);
+        const float *Wg = side ? a.Wc : a.Wr, *bg = side ? a.bc : a.br;
+        Wsm[(side * 16 + o) * 19 + (cc < C ? cc : 18)] = cc < C ? Wg[o * C + cc] : bg[o];
+    }
+    __syncthreads();
+    for (int p = tid; p < 4 * NP; p += NT * 64) {          // b[g,k,j] -> bT[g][j][slots] = [b_hi | b_hi | b_lo | 0], one (j, g) per thread-iteration
+        const int j = p % NP, g = p / NP;
+        unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
+        if (j < N)
+            for (int k = 0; k < R; ++k) {
+                const float *Wo = Wsm + (16 + g * R + k) * 19;
+                float s = Wo[18];
+                for (int c = 0; c < V; ++c) s = fmaf(Wo[c], cS[c * NP + j], fmaf(Wo[V + c], rS[c * NP + j], s));
+                s = fmaf(Wo[2 * V], cCr[j], fmaf(Wo[2 * V + 1], cCl[j], s));
+                hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
+            }
+        unsigned short *row = bT + (g * NP + j) * BTS;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0; }
-        }
+        for (int k = 0; k < 4; ++k) { row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0; }
     }
     bf16x8 af4[4];                        // a[g,k,i] as B fragments: slots [a_hi | a_lo | a_hi | 0]
     for (int g = 0; g < 4; ++g) {
         float av[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < R; ++k) {
-            const int o = g * R + k;
-            float s = a.br[o];
-            for (int c = 0; c < C; ++c) {
-                const float f = c < V ? rS[c * NP + qi] : (c < 2 * V ? cS[(c - V) * NP + qi] : (c == 2 * V ? rCr[qi] : rCl[qi]));
-                s = fmaf(a.Wr[o * C + c], f, s);
-            }
+            const float *Wo = Wsm + (g * R + k) * 19;
+            float s = Wo[18];
+            for (int c = 0; c < V; ++c) s = fmaf(Wo[c], rS[c * NP + qi], fmaf(Wo[V + c], cS[c * NP + qi], s));
+            s = fmaf(Wo[2 * V], rCr[qi], fmaf(Wo[2 * V + 1], rCl[qi], s));
             av[k] = s;
         }
 #pragma unroll

@@ -18,8 +18,10 @@ struct FusedCfg {
     static constexpr int R_BYTES = imax(NP * LDA * 2, 2 * DP * LDA * 2 + 4 * NP * BTS * 2);
     static constexpr int K_BYTES = NP * LDK * 2;
     // fp32 scratch (floats): sqk sqk2 [8][DK] qbar kbar vs0 vsL [DK] | rCr rCl cCr cCl [NP] | colpart[NT][NP] | rS cS cst [V][NP] | wsig
+    // gate-head weights [2][16][19] are staged over colpart when it is large enough (NT = 7), else in their own slot
+    static constexpr int WSM_FLOATS = 2 * 16 * 19, WSM_EXTRA = NT * NP >= WSM_FLOATS ? 0 : WSM_FLOATS;
     static __host__ __device__ constexpr int small_floats(int V) {
-        return 16 * DK + 4 * DK + 4 * NP + NT * NP + 2 * V * NP + 8;
+        return 16 * DK + 4 * DK + 4 * NP + NT * NP + 2 * V * NP + 8 + WSM_EXTRA;
     }
     static __host__ __device__ constexpr int lds_bytes(int V) { return R_BYTES + K_BYTES + 4 * small_floats(V); }
 };
