@@ -227,10 +227,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float t = half_sum32(bf2f((unsigned short)qf[s][j])); if (r == 0) colpart[w * DK + 16 * s + 8 * h + j] = t; }
+        __syncthreads();                                // Ksm staged, qbar partials written
+        key_mean_partials<NT, DK>(rS, Ksm, N, tid);     // rS is overwritten with the row means right below
         __syncthreads();
         if (tid < DK) {
             float sk = 0.f, sq = 0.f;
-            for (int j = 0; j < N; ++j) sk += bf2f(Ksm[j * LDK + tid]);
+            for (int p = 0; p < NT * 64 / DK; ++p) sk += rS[p * DK + tid];
             for (int ww = 0; ww < NT; ++ww) sq += colpart[ww * DK + tid];
             kbar[tid] = sk * invN; qbar[tid] = sq * invN;
         }
@@ -243,12 +245,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 for (int j = 0; j < 8; ++j) { const int d = 16 * s + 8 * h + j; p = fmaf(bf2f((unsigned short)qf[s][j]) * sqk[v * DK + d], kbar[d], p); }
             p += __shfl_xor(p, 32, 64);
             if (h == 0) rS[v * NP + qi] = p;
-            if (tid < NP) {
-                float c = 0.f;
-                for (int d = 0; d < DK; ++d) c = fmaf(bf2f(Ksm[tid * LDK + d]) * sqk[v * DK + d], qbar[d], c);
-                cS[v * NP + tid] = c;
-            }
         }
+        col_means_mfma<NT, DK>(cS, Ksm, sqk, qbar, V, w, r, h);
     }
     const float wv = misc[0];
 

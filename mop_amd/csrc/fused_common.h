@@ -68,6 +68,46 @@ __device__ __forceinline__ void pack_slab(bf16x8 (&Xp)[NT][2], const f32x16 (&X)
             for (int j = 0; j < 8; ++j) Xp[t][s][j] = (short)f2bf(X[t][8 * s + j]);
 }
 
+// column means of every view's score map with KS MFMAs per wave:  cS_v[j] = K[j,:] . (sqk_v * qbar)   (mean_i S_v[i,j])
+// lanes 0-7 carry the bf16 "hi" part of u_v = sqk_v * qbar for view v = lane, lanes 8-15 the "lo" remainder (fp32-accurate
+// product); wave w covers keys [32w, 32w+32).  Requires V <= 8.
+template <int NT, int DK>
+__device__ __forceinline__ void col_means_mfma(float *cS, const unsigned short *Ksm, const float *sqk, const float *qbar, int V,
+                                               int w, int r, int h) {
+    constexpr int NP = NT * 32, LDK = DK + 8;
+    const int vv = r & 7;
+    const bool act = r < 16 && vv < V, lo_part = (r >> 3) == 1;
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < DK / 16; ++s) {
+        bf16x8 bf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = 16 * s + 8 * h + e;
+            const float u = act ? sqk[vv * DK + d] * qbar[d] : 0.f;
+            const unsigned short hi = f2bf(u);
+            bf[e] = (short)(lo_part ? f2bf(u - bf2f(hi)) : hi);
+        }
+        const bf16x8 af = *(const bf16x8 *)&Ksm[(32 * w + r) * LDK + 16 * s + 8 * h];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const float tot = acc[g] + __shfl_xor(acc[g], 8, 64);
+        if (r < 8 && r < V) cS[r * NP + 32 * w + tile_row(g, h)] = tot;
+    }
+}
+// kbar[d] = mean_j K[j,d]: all threads take a strided share of the rows, partials in `part` ([threads/DK][DK])
+template <int NT, int DK>
+__device__ __forceinline__ void key_mean_partials(float *part, const unsigned short *Ksm, int N, int tid) {
+    constexpr int NPART = NT * 64 / DK, LDK = DK + 8;
+    const int d = tid % DK, p = tid / DK;
+    if (p < NPART) {
+        float s = 0.f;
+        for (int j = p; j < N; j += NPART) s += bf2f(Ksm[j * LDK + d]);
+        part[p * DK + d] = s;
+    }
+}
 
 // ---- layout of the fused path's `saved` buffer, one record per (b,h).  Inference forward writes only `ych`
 // (w * y_chain, fp32); the training forward additionally exports what the backward would otherwise recompute:
