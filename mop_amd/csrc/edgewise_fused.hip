@@ -49,6 +49,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     // REFRESH(): opaque lane id per phase so lane-derived addresses are recomputed instead of hoisted + spilled
 #define REFRESH() do { asm volatile("" : "+v"(lane)); r = lane & 31; h = lane >> 5; qi = 32 * w + r; qok = qi < N; } while (0)
     const float invN = 1.f / (float)N;
+#ifdef MOPK_STAMPS
+    unsigned long long *stamps = (unsigned long long *)a.workspace;      // 256-byte forward workspace: up to 32 stamps of workgroup 0
+    int stamp_i = 0;
+#define FSTAMP() do { if (blockIdx.x == 0 && tid == 0 && stamp_i < 32) stamps[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#else
+#define FSTAMP() do { } while (0)
+#endif
+    FSTAMP();
 
     // ---------------- P0: stage K, q fragments, scales ----------------
     {
@@ -289,6 +297,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
     };
 
+    FSTAMP();
     REFRESH();
     // ---------------- chain <- : only its log-means survive           :513-515, :521
     {
@@ -304,6 +313,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     }
     __syncthreads();
     if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
+    FSTAMP();
     REFRESH();
     // ---------------- chain -> : C-> kept as packed bf16 (for y_chain) and log C-> as packed fp16 (for the mix)
     unsigned int crp[NT][8];              // Cr (later Smix) as packed fp16
@@ -399,6 +409,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             }
         }
     }
+    FSTAMP();
     REFRESH();
     // ---------------- gate vectors                                     :323-326
     const int C = 2 * V + 2;
@@ -443,6 +454,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
     }
     __syncthreads();                      // bT complete
+    FSTAMP();
     REFRESH();
     // ---------------- score-space mix, tile by tile                    :537-547
     const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
@@ -528,6 +540,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             default: break;
         }
     }
+    FSTAMP();
     REFRESH();
     // ---------------- softmax over keys + P V0                         :551-554
     mxrow = fmaxf(mxrow, __shfl_xor(mxrow, 32, 64));
@@ -566,6 +579,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             }
         }
     }
+    FSTAMP();
 }
 
 // ------------------------------------------------------------------ host side

@@ -1,8 +1,8 @@
 // Plain scaled-dot-product attention -- fused gfx950 kernels (bf16 MFMA, fp32 accumulate, no N x N map in HBM).
 //
 // Replaces the attention core of reference BaselineMSA (attention_variants.py:42-46), MSA (components.py:61-64) and
-// MultiheadSelfAttention (whisper_mop.py:163-175) when there is no explicit mask / bias tensor (the causal flag is
-// handled in-kernel); everything else runs the generic path (attn_generic.hip).
+// MultiheadSelfAttention (whisper_mop.py:163-175): causal flag, explicit uint8 mask and additive fp32 bias are applied
+// in-kernel.  fp32-exact arithmetic and head dims other than 32 / 64 run the generic path (attn_generic.hip).
 //
 // Layout ("X layout", as in edgewise_fused.hip): a wave owns 32 queries; a 32x32 score tile is computed TRANSPOSED,
 //   S^T[key, query] = K_tile . Q^T            (v_mfma_f32_32x32x16_bf16: A = K rows from LDS, B = q fragments in registers)
@@ -41,10 +41,30 @@ __device__ __forceinline__ void fa_mix_grad(float s1, float s2, float a2, float 
         c1 = 1.f - g_or + g_or * p1; c2 = a2 + g_or * (1.f - p1);
     }
 }
+// optional explicit mask (uint8, 0 = blocked) and additive fp32 bias, element (b,h,i,j)      (whisper_mop.py:166-170, :202-205)
+struct FaMB { const uint8_t *mask; const float *bias; };
+__device__ __forceinline__ FaMB fa_mb(const MopkSdpaArgs &a, int b, int hh) {
+    FaMB m;
+    m.mask = a.mask ? a.mask + b * a.mask_sb + hh * a.mask_sh : nullptr;
+    m.bias = a.bias ? a.bias + b * a.bias_sb + hh * a.bias_sh : nullptr;
+    return m;
+}
+// one element: logit (base-2 units) -> logit + bias, or FA_NEG when blocked.  Written as selects on unconditionally loaded
+// values (indices clamped into range): a per-lane branch around an element write of the accumulator vector is miscompiled
+// by hipcc 7.2 (the taken path clobbers the other 15 elements).
+__device__ __forceinline__ float fa_apply_mb(float z, const FaMB &m, const MopkSdpaArgs &a, int i, int j, bool &blocked) {
+    const int ic = min(i, a.N - 1), jc = min(j, a.N - 1);
+    float bz = 0.f;
+    unsigned int keep = 1;
+    if (m.bias) bz = m.bias[(int64_t)ic * a.bias_si + jc] * FA_LOG2E;          // wave-uniform pointer tests
+    if (m.mask) keep = m.mask[(int64_t)ic * a.mask_si + jc];
+    blocked = keep == 0;
+    return blocked ? FA_NEG : z + bz;
+}
 }  // namespace
 
 // ------------------------------------------------------------------ forward
-template <int DK, typename IOT, bool CAUSAL, bool DUAL>
+template <int DK, typename IOT, bool CAUSAL, bool DUAL, bool MB>
 __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_fwd_kernel(MopkSdpaArgs a, float *lse, FaDual u) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vt[DK * FA_LDT], K2s[DUAL ? FA_KT * LDK : 8];
@@ -62,6 +82,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_fwd_kernel(MopkSdpaArgs
         fa_frags<DK, IOT>(*(bf16x8(*)[DK / 16]) & q2e, (const IOT *)u.q2.ptr + b * u.q2.sb + hh * u.q2.sh + (int64_t)qi * u.q2.sn, qok, h, c);
         k2p = (const IOT *)u.k2.ptr + b * u.k2.sb + hh * u.k2.sh;
     }
+    const FaMB mb = fa_mb(a, b, hh);
     float m = FA_NEG, l = 0.f;
     f32x16 O[DT];
 #pragma unroll
@@ -85,10 +106,14 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_fwd_kernel(MopkSdpaArgs
 #pragma unroll
                 for (int g = 0; g < 16; ++g) S[s2][g] = fa_mix(S[s2][g], T2[g], u.a2, u.g_or);
             }
+            if (MB) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) { bool blk; S[s2][g] = fa_apply_mb(S[s2][g], mb, a, qi, k0 + 32 * s2 + tile_row(g, h), blk); }
+            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int j = k0 + 32 * s2 + tile_row(g, h);
-                if (j >= N || (CAUSAL && j > qi)) S[s2][g] = FA_NEG;
+                S[s2][g] = (j >= N || (CAUSAL && j > qi)) ? FA_NEG : S[s2][g];      // select, not a branch around the element write
                 mx = fmaxf(mx, S[s2][g]);
             }
         }
@@ -137,7 +162,7 @@ __global__ void sdpa_flash_delta_kernel(MopkSdpaArgs a, float *delta) {
 }
 
 // dQ: one workgroup per 128 queries, loop over key tiles
-template <int DK, typename IOT, bool CAUSAL, bool DUAL>
+template <int DK, typename IOT, bool CAUSAL, bool DUAL, bool MB>
 __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs a, const float *lse, const float *delta, FaDual u) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vs[FA_KT * LDK], Kt[DK * FA_LDT];
@@ -158,6 +183,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
         k2p = (const IOT *)u.k2.ptr + b * u.k2.sb + hh * u.k2.sh;
     }
     const float Li = qok ? lse[(int64_t)bh * N + qi] : 0.f, di = qok ? delta[(int64_t)bh * N + qi] : 0.f;
+    const FaMB mb = fa_mb(a, b, hh);
     f32x16 dQ[DT], dQ2[DUAL ? DT : 1];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dQ[dt] = fa_zero(); if (DUAL) dQ2[dt] = fa_zero(); }
@@ -180,8 +206,9 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int j = k0 + 32 * s2 + tile_row(g, h);
-                const bool ok = qok && j < N && (!CAUSAL || j <= qi);
-                const float z = DUAL ? fa_mix(S[g], T2[g], u.a2, u.g_or) : S[g];
+                bool ok = qok && j < N && (!CAUSAL || j <= qi);
+                float z = DUAL ? fa_mix(S[g], T2[g], u.a2, u.g_or) : S[g];
+                if (MB) { bool blk; z = fa_apply_mb(z, mb, a, qi, j, blk); ok = ok && !blk; }
                 const float p = ok ? __builtin_amdgcn_exp2f(z - Li) : 0.f;
                 const float dz = p * (dP[g] - di) * sc;          // d logits / sqrt(dk)
                 if (DUAL) { float c1, c2; fa_mix_grad(S[g], T2[g], u.a2, u.g_or, c1, c2); dS[g] = dz * c1; dS2[g] = dz * c2; }
@@ -200,7 +227,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
 }
 
 // dK, dV: one workgroup per 128 keys (a lane owns a key), loop over query tiles
-template <int DK, typename IOT, bool CAUSAL, bool DUAL>
+template <int DK, typename IOT, bool CAUSAL, bool DUAL, bool MB>
 __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs a, const float *lse, const float *delta, FaDual u) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Qs[FA_KT * LDK], Gs[FA_KT * LDK], Qt[DK * FA_LDT], Gt[DK * FA_LDT];
@@ -224,6 +251,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
     f32x16 dK[DT], dV[DT], dK2[DUAL ? DT : 1];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dK[dt] = fa_zero(); dV[dt] = fa_zero(); if (DUAL) dK2[dt] = fa_zero(); }
+    const FaMB mb = fa_mb(a, b, hh);
     const int nqt = (N + FA_KT - 1) / FA_KT;
     for (int qt = CAUSAL ? k0 / FA_KT : 0; qt < nqt; ++qt) {      // causal: queries before this key block see none of its keys
         const int i0 = qt * FA_KT;
@@ -247,8 +275,9 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int il = 32 * s2 + tile_row(g, h), i = i0 + il;
-                const bool ok = kok && i < N && (!CAUSAL || kj <= i);
-                const float z = DUAL ? fa_mix(S[g], T2[g], u.a2, u.g_or) : S[g];
+                bool ok = kok && i < N && (!CAUSAL || kj <= i);
+                float z = DUAL ? fa_mix(S[g], T2[g], u.a2, u.g_or) : S[g];
+                if (MB) { bool blk; z = fa_apply_mb(z, mb, a, i, kj, blk); ok = ok && !blk; }
                 const float p = ok ? __builtin_amdgcn_exp2f(z - Ls[il]) : 0.f;
                 P[g] = p;
                 const float dz = p * (dP[g] - Ds[il]) * FA_LN2;   // Q' = q log2(e)/sqrt(dk)  ->  dK = (dS ln2)^T Q'
@@ -277,7 +306,6 @@ static bool fa_aligned(const MopkView4 &v, int es) {
 }
 int sdpa_flash_supported(const MopkSdpaArgs *a, bool bwd) {
     if (a->precision != MOPK_PREC_BF16) return 0;                 // fp32-exact arithmetic stays on the generic path
-    if (a->mask || a->bias) return 0;                             // explicit mask / bias tensors: generic path
     if (a->dk != 32 && a->dk != 64) return 0;
     const int es = a->io_dtype == MOPK_BF16 ? 2 : 4;
     if (!fa_aligned(a->q, es) || !fa_aligned(a->k, es) || !fa_aligned(a->v, es) || !fa_aligned(a->y, es)) return 0;
@@ -287,16 +315,20 @@ int sdpa_flash_supported(const MopkSdpaArgs *a, bool bwd) {
 size_t sdpa_flash_saved_bytes(const MopkSdpaArgs *a) { return (size_t)a->B * a->H * a->N * sizeof(float) + 256; }   // row log-sum-exp
 size_t sdpa_flash_ws_bytes(const MopkSdpaArgs *a) { return (size_t)a->B * a->H * a->N * sizeof(float) + 256; }      // delta
 
-#define FA_LAUNCH4(KERNEL, DK_, IOT_, DUAL_, GRID, ...)                                                        \
-    do { if (a->causal) hipLaunchKernelGGL((KERNEL<DK_, IOT_, true, DUAL_>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__);   \
-         else hipLaunchKernelGGL((KERNEL<DK_, IOT_, false, DUAL_>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__); } while (0)
-#define FA_DISPATCH(KERNEL, DUAL_, GRID, ...)                                                                  \
+#define FA_LAUNCH4(KERNEL, DK_, IOT_, DUAL_, MB_, GRID, ...)                                                   \
+    do { if (a->causal) hipLaunchKernelGGL((KERNEL<DK_, IOT_, true, DUAL_, MB_>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__);   \
+         else hipLaunchKernelGGL((KERNEL<DK_, IOT_, false, DUAL_, MB_>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__); } while (0)
+#define FA_DISPATCH5(KERNEL, DUAL_, MB_, GRID, ...)                                                            \
     do {                                                                                                       \
-        if (a->io_dtype == MOPK_BF16) { if (a->dk == 64) FA_LAUNCH4(KERNEL, 64, unsigned short, DUAL_, GRID, __VA_ARGS__);   \
-                                        else FA_LAUNCH4(KERNEL, 32, unsigned short, DUAL_, GRID, __VA_ARGS__); }            \
-        else { if (a->dk == 64) FA_LAUNCH4(KERNEL, 64, float, DUAL_, GRID, __VA_ARGS__);                         \
-               else FA_LAUNCH4(KERNEL, 32, float, DUAL_, GRID, __VA_ARGS__); }                                   \
+        if (a->io_dtype == MOPK_BF16) { if (a->dk == 64) FA_LAUNCH4(KERNEL, 64, unsigned short, DUAL_, MB_, GRID, __VA_ARGS__);   \
+                                        else FA_LAUNCH4(KERNEL, 32, unsigned short, DUAL_, MB_, GRID, __VA_ARGS__); }            \
+        else { if (a->dk == 64) FA_LAUNCH4(KERNEL, 64, float, DUAL_, MB_, GRID, __VA_ARGS__);                    \
+               else FA_LAUNCH4(KERNEL, 32, float, DUAL_, MB_, GRID, __VA_ARGS__); }                              \
     } while (0)
+// explicit mask / bias tensors exist for the plain (non-DUAL) kernels only
+#define FA_DISPATCH(KERNEL, DUAL_, GRID, ...)                                                                  \
+    do { if (!(DUAL_) && (a->mask || a->bias)) FA_DISPATCH5(KERNEL, false, true, GRID, __VA_ARGS__);            \
+         else FA_DISPATCH5(KERNEL, DUAL_, false, GRID, __VA_ARGS__); } while (0)
 
 int sdpa_flash_fwd(const MopkSdpaArgs *a, hipStream_t st) {
     if (!sdpa_flash_supported(a, false)) return MOPK_ERR_UNSUPPORTED;

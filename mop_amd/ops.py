@@ -171,6 +171,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
         ws = _bytes(256 if path == L.PATH_FUSED else lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+        LAST_PATH["_fwd_ws"] = ws  # kept for diagnostics (stamp builds read it back)
         with _timed("edgewise_fwd"):
             rc = lib.mopk_edgewise_lowrank_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_lowrank_fwd")

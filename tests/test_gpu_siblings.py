@@ -299,6 +299,40 @@ def test_crossview_fused_default_matches_generic(causal):
         assert float((a_ - b_).abs().max()) / max(float(b_.abs().max()), 1e-6) <= 4e-2
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_sdpa_flash_mask_and_bias_tensors(causal):
+    """explicit uint8 mask + additive bias applied inside the fused kernels (Whisper attn_bias, arbitrary BaselineMSA masks)."""
+    import mop_amd
+    from mop_amd import ops, _lib
+    mop_amd.set_precision("bf16")
+    B, N, H, dk = 2, 150, 3, 64
+    g = torch.Generator(device="cuda").manual_seed(7)
+    qkv = torch.randn(B, N, 3, H, dk, device="cuda", generator=g)
+    dy = torch.randn(B, N, H * dk, device="cuda", generator=g)
+    mask = (torch.rand(B, 1, N, N, device="cuda", generator=g) > 0.3)
+    mask[..., torch.arange(N), torch.arange(N)] = True                      # keep the diagonal: no fully blocked row
+    bias = 0.5 * torch.randn(1, H, N, N, device="cuda", generator=g)
+    res = {}
+    for path in ("fused", "generic"):
+        ops.set_path(path)
+        t = qkv.to(torch.bfloat16).requires_grad_(True)
+        y = ops.sdpa_core(t[:, :, 0], t[:, :, 1], t[:, :, 2], attn_mask=mask, bias=bias, causal=causal)
+        y.backward(dy.to(torch.bfloat16))
+        res[path] = (y.float(), t.grad.float())
+        assert ops.LAST_PATH["sdpa_fwd"] == (_lib.PATH_FUSED if path == "fused" else _lib.PATH_GENERIC)
+    ops.set_path("auto")
+    t = qkv.to(torch.bfloat16).float().requires_grad_(True)
+    q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+    att = (q @ k.transpose(-2, -1)) / dk ** 0.5 + bias
+    keep = mask & (torch.tril(torch.ones(N, N, dtype=torch.bool, device="cuda")) if causal else True)
+    yr = (att.masked_fill(~keep, float("-inf")).softmax(-1) @ v).transpose(1, 2).reshape(B, N, H * dk)
+    yr.backward(dy.to(torch.bfloat16).float())
+    for path in ("fused", "generic"):
+        y, gr = res[path]
+        assert float((y - yr.detach()).abs().max()) <= 1e-2 * max(1.0, float(yr.detach().abs().max())), path
+        assert float((gr - t.grad).abs().max()) / float(t.grad.abs().max()) <= 3e-2, path
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)
