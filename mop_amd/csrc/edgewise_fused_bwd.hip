@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             f32x16 S = s_tile(qe, t);
             if (32 * t + 32 > N) {
 #pragma unroll
-                for (int g = 0; g < 16; ++g) if (32 * t + tile_row(g, h) >= N) S[g] = NEG;
+                for (int g = 0; g < 16; ++g) S[g] = (32 * t + tile_row(g, h) >= N) ? NEG : S[g];     // select (no per-lane branch around a vector element write)
             }
             float tm = NEG;
 #pragma unroll
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int g = 0; g < 16; ++g) S[g] = __builtin_amdgcn_exp2f(S[g] - c);
         if (32 * t + 32 > N) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) if (32 * t + tile_row(g, h) >= N) S[g] = 0.f;
+            for (int g = 0; g < 16; ++g) S[g] = (32 * t + tile_row(g, h) >= N) ? 0.f : S[g];
         }
         return S;
     };
