@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct BwdWs {
     unsigned char *base;     // workspace base
     size_t stride;           // bytes per workgroup
-    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oAcc, oDW, oDA, oStamp;
+    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oDW, oStamp;
 };
 enum { S_CF = 0, S_CB, S_C3, S_L, S_DP, S_SM, S_DIR };   // S_DIR .. S_DIR+V-1 (direct score gradients per view), then S_DL(V) .. +V-1
 __host__ __device__ constexpr int S_DL(int V) { return S_DIR + V; }
@@ -46,9 +46,7 @@ struct BwdCfg {
         w.oSlots = o; o += a256((size_t)(S_DL(V) + V) * NT * SLOT);
         w.oStats = o; o += a256((size_t)V * NP * 2 * 4);
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
-        w.oAcc = o; o += a256((size_t)2 * V * NT * DT * 16 * 64 * 4);   // per-view dq / dk partials (write-only, summed in P11)
         w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
-        w.oDA = o; o += a256((size_t)NT * NT * 16 * 64 * 4);     // fp32 dA slab of every wave
         w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds)
         w.stride = a256(o);
         return w;
@@ -134,7 +132,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     float *stats = (float *)(ws + W.oStats);                          // [V][NP] softmax constants c_v[i] (log2 of the row sum of 2^S')
     const float *cstats = stats;                                      // read side (SAVED: the forward's copy)
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
-    float *dqacc = (float *)(ws + W.oAcc), *dkacc = dqacc + (size_t)a.V * NT * DT * 16 * 64;   // [V][NT][DT*16][64]
     float *dwp = (float *)(ws + W.oDW);
     auto slot = [&](int s) -> u32x4 * {
         if (SAVED && (s == S_CF || s == S_CB))       // read-only in this mode
