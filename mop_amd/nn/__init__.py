@@ -7,3 +7,4 @@ from .quartet_attn_patch import CausalSelfAttention, TransformerConfig  # noqa: 
 from .vit_mop import ViT_MoP  # noqa: F401
 from .whisper_mop import (EncoderBlock, FuseExcInh2D, Kernels2D, MoP2D, MultiheadSelfAttention,  # noqa: F401
                           ViewsConv2D, WhisperConfig)
+from .vit_edgewise import BlockEdgewise, ViTEdgewise  # noqa: F401

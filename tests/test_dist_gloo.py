@@ -65,3 +65,48 @@ def test_shard_batch_covers_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [e - s for s, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mop_amd.parallel import shard_batch
+    from mop_amd.training import DataParallelStep, make_optimizer_and_schedule
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    x, y = torch.randn(12, 8), torch.randn(12, 3)
+    opt, sched = make_optimizer_and_schedule(m, lr=1e-2, weight_decay=0.0, steps=4, warmup_frac=0.25)
+    step = DataParallelStep(m, opt, torch.nn.functional.mse_loss, sched)
+    s, e = shard_batch(12, rank, world)
+    for _ in range(4):
+        step(x[s:e], y[s:e])
+    q.put((rank, [p.detach().numpy().copy() for p in m.parameters()]))      # by value: the process exits before the parent reads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_matches_single_process_world2():
+    """2 ranks x half batch with the flat gradient all-reduce == 1 process on the full batch (equal shards, mean loss)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from mop_amd.training import DataParallelStep, make_optimizer_and_schedule
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+    x, y = torch.randn(12, 8), torch.randn(12, 3)
+    opt, sched = make_optimizer_and_schedule(m, lr=1e-2, weight_decay=0.0, steps=4, warmup_frac=0.25)
+    step = DataParallelStep(m, opt, torch.nn.functional.mse_loss, sched)
+    for _ in range(4):
+        step(x, y)
+    for a, b, c in zip(m.parameters(), res[0], res[1]):
+        assert (b == c).all()                                       # ranks stay bit-identical
+        assert torch.allclose(a.detach(), torch.from_numpy(b), atol=1e-6)

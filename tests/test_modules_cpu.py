@@ -131,3 +131,26 @@ def test_whisper_encoder_block_state_dict(name):
     assert set(sd) == set(ref)
     for k, v in ref.items():
         assert tuple(sd[k].shape) == tuple(v.shape), k
+
+
+def test_vit_edgewise_state_dict_layout_and_checkpoint_roundtrip(tmp_path):
+    """parameter names of the reference's ViTEdgewise (experiments/cifar100_edgewise_gates.py:377-452) and its checkpoint dict."""
+    from mop_amd.nn import ViTEdgewise
+    from mop_amd.training import load_checkpoint, make_optimizer_and_schedule, save_checkpoint
+    m = ViTEdgewise(dim=64, depth=2, heads=4, n_classes=10, n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2)
+    keys = set(m.state_dict())
+    for k in ("patch.proj.weight", "pos", "ln_f.weight", "head.weight", "blocks.1.ln1.bias", "blocks.0.mlp.fc1.weight",
+              "blocks.1.attn.qkv.weight", "blocks.0.attn.edge_head.row_proj.weight", "blocks.0.attn.chain_value_logit"):
+        assert k in keys, k
+    assert m.pos.shape == (1, 64, 64) and m.blocks[1].dp1.drop_prob > m.blocks[0].dp1.drop_prob == 0.0
+    opt, sched = make_optimizer_and_schedule(m, lr=3e-3, weight_decay=5e-2, steps=10, warmup_frac=0.2)
+    lrs = []
+    for _ in range(10):
+        opt.step(); sched.step(); lrs.append(opt.param_groups[0]["lr"])
+    assert lrs[0] < lrs[1] <= 3e-3 + 1e-12 and lrs[-1] < lrs[2]          # linear warm-up, then cosine decay
+    path = str(tmp_path / "ck.pt")
+    save_checkpoint(m, opt, 3, 0.5, path)
+    m2 = ViTEdgewise(dim=64, depth=2, heads=4, n_classes=10, n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2)
+    ck = load_checkpoint(m2, None, path)
+    assert ck["epoch"] == 3 and set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
