@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 100 /* 0.1.0 */
+#define MOPK_VERSION 110 /* 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
