@@ -246,27 +246,29 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, c); pack_tile(Xp[t][0], Xp[t][1], A); }
         }
         for (int m = 1; m < V; ++m) {
-            if (SAVE) {                       // export the prefix product T_{m-1}^T (AT image) for the backward's dA GEMMs
-                __syncthreads();              // previous step's readers of AT are done
-#pragma nounroll
-                for (int t = 0; t < NT; ++t) {
-                    bf16x8 lo = Xp[0][0], hi = Xp[0][1];
-                    switch (t) {
-#define MOPK_GP(K_) case K_: if (K_ < NT) { lo = Xp[K_ < NT ? K_ : 0][0]; hi = Xp[K_ < NT ? K_ : 0][1]; } break;
-                        MOPK_GP(1) MOPK_GP(2) MOPK_GP(3) MOPK_GP(4) MOPK_GP(5) MOPK_GP(6)
-#undef MOPK_GP
-                        default: break;
-                    }
-                    store_AT_tile(t, lo, hi);
-                }
-                __syncthreads();
+            if (SAVE) {
+                // export the prefix product for the backward's dA GEMMs in "row slab" order: wave w' of the backward reads, per
+                // lane (key a = 32w' + r'), the fragments {T[i, a] : i} -> [wave w'][chunk q][lane], 16 B each.  That is the
+                // TRANSPOSE of the tiles this wave holds (lane = query, registers = keys); it is taken on the matrix core:
+                // D = X . I (two MFMAs per tile with identity B fragments) comes back with lane = key, registers = queries,
+                // and its packed halves are exactly chunks q = 2w, 2w+1 of wave t's slab.  No LDS round trip, no barrier.
                 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-                u4 *out = (u4 *)(svb + (forward ? SL.oT : SL.oU) + (size_t)(m - 1) * NP * LDA * 2);
-                // "row slab" order: [wave w'][chunk q = 2t+s][lane] = 16 B at AT[32w' + r'][32t + 16s + 8h'], i.e. exactly
-                // the B-operand fragments wave w' of the backward loads -> one coalesced 1 KiB access per fragment
-                for (int c8 = tid; c8 < NT * 2 * NT * 64; c8 += NT * 64) {
-                    const int L = c8 & 63, q = (c8 >> 6) % (2 * NT), ws_ = (c8 >> 6) / (2 * NT);
-                    out[c8] = *(const u4 *)&AT[(32 * ws_ + (L & 31)) * LDA + 16 * q + 8 * (L >> 5)];
+                u4 *out = (u4 *)(svb + (forward ? SL.oT : SL.oU) + (size_t)(m - 1) * NP * LDA * 2) + lane;
+                bf16x8 idl, idh;              // B fragments of the 32 x 32 identity in the accumulator's k order
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    idl[e] = (short)(r == tile_row(e, h) ? 0x3f80 : 0);          // bf16(1.0)
+                    idh[e] = (short)(r == 16 + tile_row(e, h) ? 0x3f80 : 0);
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x16 tr = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xp[t][0], idl, tr, 0, 0, 0);
+                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xp[t][1], idh, tr, 0, 0, 0);
+                    bf16x8 lo, hi;
+                    pack_tile(lo, hi, tr);    // exact: every entry is one bf16 value times 1.0
+                    out[((size_t)t * 2 * NT + 2 * w) * 64] = __builtin_bit_cast(u4, lo);
+                    out[((size_t)t * 2 * NT + 2 * w + 1) * 64] = __builtin_bit_cast(u4, hi);
                 }
             }
             {
