@@ -20,6 +20,9 @@
 // HBM traffic per (b,h): q,k,v in + y out (~100 KB) for 0.9 GFLOP -> MFMA/VALU bound.
 #include "fused_common.h"
 
+#ifdef MOPK_WHATIF_NOBAR       // timing experiment only (results are wrong)
+#define __syncthreads() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
 namespace mopk {
 
 template <int NT, int DK, typename IOT, bool SAVE>
@@ -55,6 +58,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #define FSTAMP() do { if (blockIdx.x == 0 && tid == 0 && stamp_i < 32) stamps[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
 #else
 #define FSTAMP() do { } while (0)
+#endif
+#ifdef MOPK_STAMPS2
+#define FSTAMP2(c_) do { if (c_) FSTAMP(); } while (0)
+#else
+#define FSTAMP2(c_) do { } while (0)
 #endif
     FSTAMP();
 
@@ -148,7 +156,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     // only tiles that contain keys >= N pay for the mask
     auto row_const = [&](const bf16x8 (&qe)[KS]) -> float {
         float m = NEG, l = 0.f;
-#pragma nounroll
+#pragma unroll 2
         for (int t = 0; t < NT; ++t) {
             f32x16 S = s_tile(qe, t);
             if (32 * t + 32 > N) {
@@ -184,6 +192,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         for (int j = 0; j < 8; ++j) { lo[j] = (short)f2bf(x[j]); hi[j] = (short)f2bf(x[8 + j]); }
     };
     auto store_AT_tile = [&](int t, bf16x8 lo, bf16x8 hi) {      // AT[key][perm(query)] for one tile
+#ifdef MOPK_WHATIF_NOSTORE     // timing experiment only (results are wrong)
+        if (a.B > 0) return;
+#endif
         unsigned short *base = AT + (32 * t + 4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -273,18 +284,23 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             }
             {
                 const int v = forward ? m : V - 1 - m;
+                FSTAMP2(forward && m == 1);
                 bf16x8 qe[KS];
                 make_qe2(qe, v);
                 const float c = view_const(qe, v);
+                FSTAMP2(forward && m == 1);
                 __syncthreads();              // previous step's readers of AT are done
-#pragma nounroll
+                FSTAMP2(forward && m == 1);
+#pragma unroll 2
                 for (int t = 0; t < NT; ++t) {
                     const f32x16 A = a_tile(qe, t, c);
                     bf16x8 lo, hi;
                     pack_tile(lo, hi, A);
                     store_AT_tile(t, lo, hi);
                 }
+                FSTAMP2(forward && m == 1);
                 __syncthreads();
+                FSTAMP2(forward && m == 1);
             }
             if (m < V - 1) {
                 bf16x8 Xn[NT][2];
@@ -292,6 +308,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 for (int to = 0; to < NT; ++to) { const f32x16 acc = gemm_tile(to, Xp); pack_tile(Xn[to][0], Xn[to][1], acc); }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
+                FSTAMP2(forward && m == 1);
             } else {
 #pragma unroll
                 for (int to = 0; to < NT; ++to) { f32x16 acc = gemm_tile(to, Xp); epi(to, acc); }
