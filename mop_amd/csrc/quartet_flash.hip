@@ -1,7 +1,7 @@
 // Quartet causal attention core -- fused gfx950 kernels (bf16 MFMA, fp32 accumulate, no T x T map in HBM).
 //
-// Replaces reference mop/models/quartet_attn_patch.py:88-121 when there is no additive attention_mask and the attention
-// weights are not requested:  qk and q2k2 scores are z-normalised over the FULL row (all T keys, unbiased std), mixed
+// Replaces reference mop/models/quartet_attn_patch.py:88-121 when the attention weights are not requested (the additive
+// attention_mask is applied in-kernel):  qk and q2k2 scores are z-normalised over the FULL row (all T keys, unbiased std), mixed
 //   scores = (1 - m) z1 + m (z1 z2) quartet_scale          (use_quartet)        |   scores = z1   (otherwise, eps 1e-5)
 // causally masked, soft-maxed and applied to v.  Because the row statistics need every key, the forward is two passes
 // (statistics, then an online-softmax pass as in sdpa_flash.hip); the backward of the z-norm adds dense row corrections,
@@ -40,6 +40,11 @@ __device__ __forceinline__ float qt_logit(float s1, float s2, const QtNorm &n1, 
     if (!DUAL) { z2 = 0.f; return z1; }
     z2 = (s2 - n2.mu) * n2.inv;
     return z1 * ((1.f - q.m) + q.mq * z2);                        // :104-106
+}
+// additive attention_mask (:115-116), element (b,h,i,j); indices clamped so the load is unconditional (no per-lane branch)
+template <bool AM>
+__device__ __forceinline__ float qt_am(const MopkQuartetArgs &a, const float *base, int i, int j) {
+    return AM ? base[(int64_t)min(i, a.T - 1) * a.am_si + min(j, a.T - 1)] : 0.f;
 }
 }  // namespace
 
@@ -94,7 +99,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_stats_kernel(MopkQuartetArgs a,
 }
 
 // ------------------------------------------------------------------ pass 2: mixed logits, causal online softmax, A v
-template <int DK, typename IOT, bool DUAL>
+template <int DK, typename IOT, bool DUAL, bool AM>
 __global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, const float *stats, float *lse) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vt[DK * FA_LDT], K2s[DUAL ? FA_KT * LDK : 8];
@@ -104,6 +109,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, c
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
+    const float *amp = AM ? a.add_mask + b * a.am_sb + hh * a.am_sh : nullptr;
     bf16x8 qe[DK / 16], q2e[DUAL ? DK / 16 : 1];
     fa_frags<DK, IOT>(qe, (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn, qok, h, sc);
     const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh, *vp = (const IOT *)a.v.ptr + b * a.v.sb + hh * a.v.sh, *k2p = nullptr;
@@ -136,7 +142,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, c
             for (int g = 0; g < 16; ++g) {
                 const int j = k0 + 32 * hf + tile_row(g, h);
                 float z1, z2;
-                const float lg = qt_logit<DUAL>(S[hf][g], T2[g], n1, n2, qs, z1, z2) * FA_LOG2E;
+                const float lg = (qt_logit<DUAL>(S[hf][g], T2[g], n1, n2, qs, z1, z2) + qt_am<AM>(a, amp, qi, j)) * FA_LOG2E;
                 S[hf][g] = (j >= N || j > qi) ? FA_NEG : lg;
                 mx = fmaxf(mx, S[hf][g]);
             }
@@ -185,7 +191,7 @@ __global__ void qt_delta_kernel(MopkQuartetArgs a, float *delta) {          // d
 }
 
 // row sums of the z-norm backward over the causal region + per-block partials of the two scalar gradients
-template <int DK, typename IOT, bool DUAL>
+template <int DK, typename IOT, bool DUAL, bool AM>
 __global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
                                                                float *rows, float *spart) {
     constexpr int LDK = DK + 8;
@@ -197,6 +203,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
+    const float *amp = AM ? a.add_mask + b * a.am_sb + hh * a.am_sh : nullptr;
     bf16x8 qe[DK / 16], q2e[DUAL ? DK / 16 : 1], dof[DK / 16];
     fa_frags<DK, IOT>(qe, (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn, qok, h, sc);
     fa_frags<DK, IOT>(dof, (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)qi * a.dy.sn, qok, h, 1.f);
@@ -228,7 +235,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a
                 const int j = k0 + 32 * hf + tile_row(g, h);
                 if (qok && j < N && j <= qi) {
                     float z1, z2;
-                    const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2);
+                    const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2) + qt_am<AM>(a, amp, qi, j);
                     const float dsc = __builtin_amdgcn_exp2f(lg * FA_LOG2E - Li) * (dP[g] - di);
                     const float dz1 = DUAL ? dsc * ((1.f - qs.m) + qs.mq * z2) : dsc;
                     A1 += dz1; B1 = fmaf(dz1, S1[g] - n1.mu, B1);
@@ -269,7 +276,7 @@ __device__ __forceinline__ float qt_dscore(float dz, float s, const QtNorm &n) {
 }
 
 // dQ (and dQ2): per query block over ALL key tiles (the z-norm correction is dense)
-template <int DK, typename IOT, bool DUAL>
+template <int DK, typename IOT, bool DUAL, bool AM>
 __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
                                                            const float *rows) {
     constexpr int DT = DK / 32, LDK = DK + 8;
@@ -281,6 +288,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, co
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
+    const float *amp = AM ? a.add_mask + b * a.am_sb + hh * a.am_sh : nullptr;
     bf16x8 qe[DK / 16], q2e[DUAL ? DK / 16 : 1], dof[DK / 16];
     fa_frags<DK, IOT>(qe, (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn, qok, h, sc);
     fa_frags<DK, IOT>(dof, (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)qi * a.dy.sn, qok, h, 1.f);
@@ -315,7 +323,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, co
             for (int g = 0; g < 16; ++g) {
                 const int j = k0 + 32 * hf + tile_row(g, h);
                 float z1, z2, dz1 = 0.f, dz2 = 0.f;
-                const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2);
+                const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2) + qt_am<AM>(a, amp, qi, j);
                 if (j <= qi) {                                    // causal region: the soft-max sees this edge
                     const float dsc = __builtin_amdgcn_exp2f(lg * FA_LOG2E - Li) * (dP[g] - di);
                     dz1 = DUAL ? dsc * ((1.f - qs.m) + qs.mq * z2) : dsc;
@@ -338,7 +346,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, co
 }
 
 // dK, dK2, dV: per key block (lane = key) over ALL query tiles
-template <int DK, typename IOT, bool DUAL>
+template <int DK, typename IOT, bool DUAL, bool AM>
 __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
                                                             const float *rows) {
     constexpr int DT = DK / 32, LDK = DK + 8;
@@ -351,6 +359,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, c
     const bool kok = kj < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
+    const float *amp = AM ? a.add_mask + b * a.am_sb + hh * a.am_sh : nullptr;
     const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh, *gp = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh, *q2p = nullptr;
     bf16x8 kf[DK / 16], vf[DK / 16], k2f[DUAL ? DK / 16 : 1];
     fa_frags<DK, IOT>(kf, (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh + (int64_t)kj * a.k.sn, kok, h, 1.f);
@@ -395,7 +404,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, c
                 const float4 ra = Rs[il][0], rb = Rs[il][1], rc = Rs[il][2];
                 const QtNorm n1{ra.x, ra.y, ra.z, ra.w, rb.x}, n2{rb.y, rb.z, rb.w, rc.x, rc.y};
                 float z1, z2, dz1 = 0.f, dz2 = 0.f, p = 0.f;
-                const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2);
+                const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2) + qt_am<AM>(a, amp, i, kj);
                 const bool ok = kok && i < N;
                 if (ok && kj <= i) {
                     p = __builtin_amdgcn_exp2f(lg * FA_LOG2E - rc.z);
@@ -441,7 +450,7 @@ QtBufs qt_carve_flash(void *saved, void *ws, const MopkQuartetArgs *a) {
 
 int qt_flash_supported(const MopkQuartetArgs *a, bool bwd) {
     if (a->precision != MOPK_PREC_BF16) return 0;
-    if (a->add_mask || a->attn) return 0;                          // additive mask / returned attention weights: generic path
+    if (a->attn) return 0;                                         // returned attention weights: generic path
     if (a->dh != 32 && a->dh != 64) return 0;
     const int es = a->io_dtype == MOPK_BF16 ? 2 : 4;
     if (!qt_al(a->q, es) || !qt_al(a->k, es) || !qt_al(a->v, es) || !qt_al(a->y, es)) return 0;
@@ -455,27 +464,28 @@ int qt_flash_supported(const MopkQuartetArgs *a, bool bwd) {
 size_t qt_flash_saved_bytes(const MopkQuartetArgs *a) { return qt_carve_flash(nullptr, nullptr, a).nsaved + 256; }
 size_t qt_flash_ws_bytes(const MopkQuartetArgs *a) { return qt_carve_flash(nullptr, nullptr, a).nwork + 256; }
 
-#define QT_LAUNCH(KERNEL, GRID, ...)                                                                              \
-    do {                                                                                                          \
-        const dim3 blk_(FA_NW * 64);                                                                              \
-        if (a->io_dtype == MOPK_BF16) {                                                                           \
-            if (a->dh == 64) { if (a->use_quartet) hipLaunchKernelGGL((KERNEL<64, unsigned short, true>), GRID, blk_, 0, st, __VA_ARGS__);   \
-                               else hipLaunchKernelGGL((KERNEL<64, unsigned short, false>), GRID, blk_, 0, st, __VA_ARGS__); }               \
-            else { if (a->use_quartet) hipLaunchKernelGGL((KERNEL<32, unsigned short, true>), GRID, blk_, 0, st, __VA_ARGS__);              \
-                   else hipLaunchKernelGGL((KERNEL<32, unsigned short, false>), GRID, blk_, 0, st, __VA_ARGS__); }                          \
-        } else {                                                                                                  \
-            if (a->dh == 64) { if (a->use_quartet) hipLaunchKernelGGL((KERNEL<64, float, true>), GRID, blk_, 0, st, __VA_ARGS__);            \
-                               else hipLaunchKernelGGL((KERNEL<64, float, false>), GRID, blk_, 0, st, __VA_ARGS__); }                        \
-            else { if (a->use_quartet) hipLaunchKernelGGL((KERNEL<32, float, true>), GRID, blk_, 0, st, __VA_ARGS__);                       \
-                   else hipLaunchKernelGGL((KERNEL<32, float, false>), GRID, blk_, 0, st, __VA_ARGS__); }                                   \
-        }                                                                                                         \
+#define QT_LAUNCH_T(KERNEL, DK_, IOT_, GRID, ...)                                                                \
+    do { if (a->use_quartet) hipLaunchKernelGGL((KERNEL<DK_, IOT_, true>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__);      \
+         else hipLaunchKernelGGL((KERNEL<DK_, IOT_, false>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__); } while (0)
+#define QT_LAUNCH_TA(KERNEL, DK_, IOT_, GRID, ...)                                                               \
+    do { if (a->use_quartet) { if (a->add_mask) hipLaunchKernelGGL((KERNEL<DK_, IOT_, true, true>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__);   \
+                               else hipLaunchKernelGGL((KERNEL<DK_, IOT_, true, false>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__); }           \
+         else { if (a->add_mask) hipLaunchKernelGGL((KERNEL<DK_, IOT_, false, true>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__);                \
+                else hipLaunchKernelGGL((KERNEL<DK_, IOT_, false, false>), GRID, dim3(FA_NW * 64), 0, st, __VA_ARGS__); } } while (0)
+#define QT_DISPATCH(MACRO, KERNEL, GRID, ...)                                                                    \
+    do {                                                                                                         \
+        if (a->io_dtype == MOPK_BF16) { if (a->dh == 64) MACRO(KERNEL, 64, unsigned short, GRID, __VA_ARGS__);   \
+                                        else MACRO(KERNEL, 32, unsigned short, GRID, __VA_ARGS__); }             \
+        else { if (a->dh == 64) MACRO(KERNEL, 64, float, GRID, __VA_ARGS__); else MACRO(KERNEL, 32, float, GRID, __VA_ARGS__); }   \
     } while (0)
+#define QT_LAUNCH(KERNEL, GRID, ...) QT_DISPATCH(QT_LAUNCH_TA, KERNEL, GRID, __VA_ARGS__)
+#define QT_LAUNCH_STATS(KERNEL, GRID, ...) QT_DISPATCH(QT_LAUNCH_T, KERNEL, GRID, __VA_ARGS__)
 
 int qt_flash_fwd(const MopkQuartetArgs *a, hipStream_t st) {
     if (!qt_flash_supported(a, false)) return MOPK_ERR_UNSUPPORTED;
     const QtBufs b = qt_carve_flash(a->saved, a->workspace, a);
     const dim3 grid((a->T + FA_QB - 1) / FA_QB, a->B * a->H);
-    QT_LAUNCH(qt_stats_kernel, grid, *a, b.stats);
+    QT_LAUNCH_STATS(qt_stats_kernel, grid, *a, b.stats);
     QT_LAUNCH(qt_fwd_kernel, grid, *a, (const float *)b.stats, b.lse);
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;

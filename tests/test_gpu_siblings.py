@@ -333,6 +333,32 @@ def test_sdpa_flash_mask_and_bias_tensors(causal):
         assert float((gr - t.grad).abs().max()) / float(t.grad.abs().max()) <= 3e-2, path
 
 
+def test_quartet_fused_additive_mask_matches_generic():
+    """attention_mask (additive, reference :115-116) applied inside the fused Quartet kernels."""
+    import mop_amd
+    from mop_amd import ops, _lib
+    mop_amd.set_precision("bf16")
+    B, T, H, dh = 2, 150, 2, 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    base = [torch.randn(B, T, H, dh, device="cuda", generator=g) for _ in range(5)]
+    dy = torch.randn(B, T, H * dh, device="cuda", generator=g)
+    am = 0.7 * torch.randn(B, 1, T, T, device="cuda", generator=g)
+    res = {}
+    for path in ("fused", "generic"):
+        ops.set_path(path)
+        ts = [t.to(torch.bfloat16).requires_grad_(True) for t in base]
+        mix = torch.tensor([0.3], device="cuda", requires_grad=True)
+        qs = torch.tensor([0.8], device="cuda", requires_grad=True)
+        y = ops.quartet_core(*ts, mix, qs, am, 1e-5, True)
+        y.backward(dy.to(torch.bfloat16))
+        res[path] = [y.float()] + [t.grad.float() for t in ts]
+        assert ops.LAST_PATH["quartet_fwd"] == (_lib.PATH_FUSED if path == "fused" else _lib.PATH_GENERIC)
+    ops.set_path("auto")
+    for i, (a_, b_) in enumerate(zip(res["fused"], res["generic"])):
+        den = max(1.0, float(b_.abs().max())) if i == 0 else float(b_.abs().max())
+        assert float((a_ - b_).detach().abs().max()) / den <= (1e-2 if i == 0 else 5e-2), i
+
+
 def test_quartet_need_weights_rows_sum_to_one():
     from mop_amd.nn import CausalSelfAttention, TransformerConfig
     torch.manual_seed(0)
