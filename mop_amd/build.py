@@ -18,6 +18,8 @@ PLAIN = ["api.hip", "edgewise_generic.hip", "attn_generic.hip", "sdpa_flash.hip"
 FUSED = ["edgewise_fused.hip", "edgewise_fused_bwd.hip"]
 NTS, DKS = (1, 2, 4, 7), (16, 32, 64)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+if os.environ.get("MOPK_EXTRA_FLAGS"):  # compiler experiments, e.g. MOPK_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
+    FLAGS += os.environ["MOPK_EXTRA_FLAGS"].split()
 if os.environ.get("MOPK_WHATIF"):  # timing experiments (wrong results by construction), e.g. MOPK_WHATIF=NOBAR,NOSLOT
     FLAGS += ["-DMOPK_WHATIF_" + w for w in os.environ["MOPK_WHATIF"].split(",")]
 if os.environ.get("MOPK_STAMPS"):  # diagnostic build: s_memtime stamps per phase (never benchmark this build)
