@@ -78,5 +78,13 @@ __device__ __forceinline__ void fa_store_rows(IOT *row, const f32x16 (&acc)[DK /
             store4<IOT>(row + 32 * dt + 8 * g4 + 4 * h, acc[dt][4 * g4] * scale, acc[dt][4 * g4 + 1] * scale, acc[dt][4 * g4 + 2] * scale,
                         acc[dt][4 * g4 + 3] * scale);
 }
+// workgroup id -> (block along the token axis, (b,h)).  The grid is 1-D; ids are dealt round-robin over the 8 XCDs (each with
+// its own L2), so the bijective swizzle of cdna_hip_programming.md gives every XCD a CONTIGUOUS chunk of the (bh-major) tile
+// list: all token blocks of one (b,h) -- which re-read the same K/V (or Q/dY) -- run behind the same L2.  Speed only.
+__device__ __forceinline__ void fa_block_id(int nq, int &qb, int &bh) {
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig % 8, q = nwg / 8, rr = nwg % 8;
+    const int swz = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    qb = swz % nq; bh = swz / nq;
+}
 }  // namespace
 }  // namespace mopk

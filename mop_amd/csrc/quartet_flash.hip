@@ -54,8 +54,11 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_stats_kernel(MopkQuartetArgs a,
     constexpr int LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], K2s[DUAL ? FA_KT * LDK : 8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.T, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int qi = blockIdx.x * FA_QB + 32 * w + r;
+    const int N = a.T;
+    int qb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, qb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int qi = qb * FA_QB + 32 * w + r;
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK);
     bf16x8 qe[DK / 16], q2e[DUAL ? DK / 16 : 1];
@@ -104,8 +107,11 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, c
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vt[DK * FA_LDT], K2s[DUAL ? FA_KT * LDK : 8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.T, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int q0 = blockIdx.x * FA_QB, qi = q0 + 32 * w + r;
+    const int N = a.T;
+    int qb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, qb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int q0 = qb * FA_QB, qi = q0 + 32 * w + r;
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
@@ -198,8 +204,11 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vs[FA_KT * LDK], K2s[DUAL ? FA_KT * LDK : 8];
     __shared__ float red[2][FA_NW];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.T, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int q0 = blockIdx.x * FA_QB, qi = q0 + 32 * w + r;
+    const int N = a.T;
+    int qb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, qb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int q0 = qb * FA_QB, qi = q0 + 32 * w + r;
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
@@ -257,7 +266,8 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a
     if (tid == 0) {
         float x = 0.f, y = 0.f;
         for (int i = 0; i < FA_NW; ++i) { x += red[0][i]; y += red[1][i]; }
-        spart[((int64_t)bh * gridDim.x + blockIdx.x) * 2] = x; spart[((int64_t)bh * gridDim.x + blockIdx.x) * 2 + 1] = y;
+        const int nq = (N + FA_QB - 1) / FA_QB;
+        spart[((int64_t)bh * nq + qb) * 2] = x; spart[((int64_t)bh * nq + qb) * 2 + 1] = y;
     }
 }
 // per (b,h): fixed-order sum of the block partials; dmixture carries sigmoid'(mixture)
@@ -283,8 +293,11 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, co
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vs[FA_KT * LDK], Kt[DK * FA_LDT];
     __shared__ __attribute__((aligned(16))) unsigned short K2s[DUAL ? FA_KT * LDK : 8], K2t[DUAL ? DK * FA_LDT : 8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.T, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int q0 = blockIdx.x * FA_QB, qi = q0 + 32 * w + r;
+    const int N = a.T;
+    int qb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, qb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int q0 = qb * FA_QB, qi = q0 + 32 * w + r;
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
@@ -354,8 +367,11 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, c
     __shared__ __attribute__((aligned(16))) unsigned short Q2s[DUAL ? FA_KT * LDK : 8], Q2t[DUAL ? DK * FA_LDT : 8];
     __shared__ float4 Rs[FA_KT][3];                    // per query: (mu1, inv1, cc1, am1) (bs1, mu2, inv2, cc2) (am2, bs2, L, delta)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.T, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int k0 = blockIdx.x * FA_QB, kj = k0 + 32 * w + r;
+    const int N = a.T;
+    int kb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, kb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int k0 = kb * FA_QB, kj = k0 + 32 * w + r;
     const bool kok = kj < N;
     const float sc = rsqrtf((float)DK);
     const QtScal qs = qt_scal<DUAL>(a);
@@ -484,7 +500,8 @@ size_t qt_flash_ws_bytes(const MopkQuartetArgs *a) { return qt_carve_flash(nullp
 int qt_flash_fwd(const MopkQuartetArgs *a, hipStream_t st) {
     if (!qt_flash_supported(a, false)) return MOPK_ERR_UNSUPPORTED;
     const QtBufs b = qt_carve_flash(a->saved, a->workspace, a);
-    const dim3 grid((a->T + FA_QB - 1) / FA_QB, a->B * a->H);
+    const int nq = (a->T + FA_QB - 1) / FA_QB;
+    const dim3 grid(nq * a->B * a->H);
     QT_LAUNCH_STATS(qt_stats_kernel, grid, *a, b.stats);
     QT_LAUNCH(qt_fwd_kernel, grid, *a, (const float *)b.stats, b.lse);
     MOPK_CHECK_LAUNCH();
@@ -496,10 +513,11 @@ int qt_flash_bwd(const MopkQuartetArgs *a, hipStream_t st) {
     const int64_t rows = (int64_t)a->B * a->H * a->T;
     if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((qt_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, b.delta);
     else hipLaunchKernelGGL((qt_delta_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, b.delta);
-    const dim3 grid((a->T + FA_QB - 1) / FA_QB, a->B * a->H);
+    const int nq = (a->T + FA_QB - 1) / FA_QB;
+    const dim3 grid(nq * a->B * a->H);
     QT_LAUNCH(qt_rowsum_kernel, grid, *a, (const float *)b.stats, (const float *)b.lse, (const float *)b.delta, b.rows, b.spart);
     if (a->use_quartet)
-        hipLaunchKernelGGL(qt_scalar_sum_kernel, dim3((a->B * a->H + 63) / 64), dim3(64), 0, st, (const float *)b.spart, (int)grid.x, a->B * a->H,
+        hipLaunchKernelGGL(qt_scalar_sum_kernel, dim3((a->B * a->H + 63) / 64), dim3(64), 0, st, (const float *)b.spart, nq, a->B * a->H,
                            a->mixture, a->dmixture_part, a->dqscale_part);
     QT_LAUNCH(qt_dq_kernel, grid, *a, (const float *)b.stats, (const float *)b.lse, (const float *)b.delta, (const float *)b.rows);
     QT_LAUNCH(qt_dkv_kernel, grid, *a, (const float *)b.stats, (const float *)b.lse, (const float *)b.delta, (const float *)b.rows);

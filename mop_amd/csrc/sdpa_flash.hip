@@ -69,8 +69,11 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_fwd_kernel(MopkSdpaArgs
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vt[DK * FA_LDT], K2s[DUAL ? FA_KT * LDK : 8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.N, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int q0 = blockIdx.x * FA_QB, qi = q0 + 32 * w + r;
+    const int N = a.N;
+    int qb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, qb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int q0 = qb * FA_QB, qi = q0 + 32 * w + r;
     const bool qok = qi < N;
     const float c = rsqrtf((float)DK) * FA_LOG2E;                  // logits in base-2 units: exp2 without a multiply
     const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh, *vp = (const IOT *)a.v.ptr + b * a.v.sb + hh * a.v.sh;
@@ -168,8 +171,11 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vs[FA_KT * LDK], Kt[DK * FA_LDT];
     __shared__ __attribute__((aligned(16))) unsigned short K2s[DUAL ? FA_KT * LDK : 8], K2t[DUAL ? DK * FA_LDT : 8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.N, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int q0 = blockIdx.x * FA_QB, qi = q0 + 32 * w + r;
+    const int N = a.N;
+    int qb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, qb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int q0 = qb * FA_QB, qi = q0 + 32 * w + r;
     const bool qok = qi < N;
     const float sc = rsqrtf((float)DK), c = sc * FA_LOG2E;
     const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh, *vp = (const IOT *)a.v.ptr + b * a.v.sb + hh * a.v.sh;
@@ -234,8 +240,11 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
     __shared__ __attribute__((aligned(16))) unsigned short Q2s[DUAL ? FA_KT * LDK : 8], Q2t[DUAL ? DK * FA_LDT : 8];
     __shared__ float Ls[FA_KT], Ds[FA_KT];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int N = a.N, bh = blockIdx.y, b = bh / a.H, hh = bh % a.H;
-    const int k0 = blockIdx.x * FA_QB, kj = k0 + 32 * w + r;
+    const int N = a.N;
+    int kb, bh;
+    fa_block_id((N + FA_QB - 1) / FA_QB, kb, bh);
+    const int b = bh / a.H, hh = bh % a.H;
+    const int k0 = kb * FA_QB, kj = k0 + 32 * w + r;
     const bool kok = kj < N;
     const float c = rsqrtf((float)DK) * FA_LOG2E;
     const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh, *gp = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh;
@@ -332,7 +341,7 @@ size_t sdpa_flash_ws_bytes(const MopkSdpaArgs *a) { return (size_t)a->B * a->H *
 
 int sdpa_flash_fwd(const MopkSdpaArgs *a, hipStream_t st) {
     if (!sdpa_flash_supported(a, false)) return MOPK_ERR_UNSUPPORTED;
-    const dim3 grid((a->N + FA_QB - 1) / FA_QB, a->B * a->H);
+    const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
     FA_DISPATCH(sdpa_flash_fwd_kernel, false, grid, *a, (float *)a->saved, FaDual{});
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
@@ -344,7 +353,7 @@ int sdpa_flash_bwd(const MopkSdpaArgs *a, hipStream_t st) {
     if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
     else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
     MOPK_CHECK_LAUNCH();
-    const dim3 grid((a->N + FA_QB - 1) / FA_QB, a->B * a->H);
+    const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
     FA_DISPATCH(sdpa_flash_dq_kernel, false, grid, *a, (const float *)a->saved, (const float *)delta, FaDual{});
     MOPK_CHECK_LAUNCH();
     FA_DISPATCH(sdpa_flash_dkv_kernel, false, grid, *a, (const float *)a->saved, (const float *)delta, FaDual{});
@@ -446,7 +455,7 @@ static int dp_plain_fwd(const MopkDualPathArgs *d, const MopkView4 &q, const Mop
     MopkSdpaArgs s = dp_sdpa(d);
     s.q = q; s.k = k; s.v = v; s.y = y;
     const MopkSdpaArgs *a = &s;
-    const dim3 grid((a->N + FA_QB - 1) / FA_QB, a->B * a->H);
+    const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
     FA_DISPATCH(sdpa_flash_fwd_kernel, false, grid, *a, lse, FaDual{});
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
@@ -460,7 +469,7 @@ static int dp_plain_bwd(const MopkDualPathArgs *d, const MopkView4 &q, const Mop
     const int64_t rows = (int64_t)a->B * a->H * a->N;
     if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
     else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
-    const dim3 grid((a->N + FA_QB - 1) / FA_QB, a->B * a->H);
+    const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
     FA_DISPATCH(sdpa_flash_dq_kernel, false, grid, *a, lse, (const float *)delta, FaDual{});
     FA_DISPATCH(sdpa_flash_dkv_kernel, false, grid, *a, lse, (const float *)delta, FaDual{});
     MOPK_CHECK_LAUNCH();
@@ -476,7 +485,7 @@ int dp_flash_fwd(const MopkDualPathArgs *a, hipStream_t st) {
         MopkSdpaArgs s = dp_sdpa(a);
         s.q = a->q1; s.k = a->k1; s.v = a->v1; s.y = o1;
         FaDual u{a->q2, a->k2, MopkView4{}, MopkView4{}, a->g_and - a->beta_not * a->g_not, a->g_or};
-        const dim3 grid((a->N + FA_QB - 1) / FA_QB, a->B * a->H);
+        const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
         const MopkSdpaArgs *keep = a ? &s : nullptr;
         { const MopkSdpaArgs *a = keep; FA_DISPATCH(sdpa_flash_fwd_kernel, true, grid, *a, L.lse_m, u); }
         MOPK_CHECK_LAUNCH();
@@ -514,7 +523,7 @@ int dp_flash_bwd(const MopkDualPathArgs *a, hipStream_t st) {
         const int64_t rows = (int64_t)a->B * a->H * a->N;
         if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, s, W.delta);
         else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, st, s, W.delta);
-        const dim3 grid((a->N + FA_QB - 1) / FA_QB, a->B * a->H);
+        const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
         const MopkSdpaArgs *keep = &s;
         { const MopkSdpaArgs *a = keep; FA_DISPATCH(sdpa_flash_dq_kernel, true, grid, *a, (const float *)L.lse_m, (const float *)W.delta, u);
           FA_DISPATCH(sdpa_flash_dkv_kernel, true, grid, *a, (const float *)L.lse_m, (const float *)W.delta, u); }
