@@ -47,6 +47,38 @@ __device__ __forceinline__ void fa_stage(unsigned short *rows, unsigned short *c
         }
     }
 }
+// the same staging split in two so the global loads of tile t+1 fly while tile t is computed:
+// fa_fetch (global -> registers), fa_put (registers -> LDS images)
+template <int DK> struct FaTile { bf16x8 v[FA_KT * (DK / 8) / (FA_NW * 64)]; };
+template <int DK, typename IOT>
+__device__ __forceinline__ void fa_fetch(FaTile<DK> &f, const IOT *base, int64_t sn, int t0, int N, float scale, int tid) {
+    constexpr int CH = DK / 8, NC = FA_KT * CH / (FA_NW * 64);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int c = tid + k * FA_NW * 64, j = c / CH, dc = c % CH;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t0 + j < N) v = load8_bf16<IOT>(base + (int64_t)(t0 + j) * sn + dc * 8);
+        if (scale != 1.f) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((unsigned short)v[e]) * scale);
+        }
+        f.v[k] = v;
+    }
+}
+template <int DK, bool ROWS, bool COLS>
+__device__ __forceinline__ void fa_put(unsigned short *rows, unsigned short *cols, const FaTile<DK> &f, int tid) {
+    constexpr int CH = DK / 8, NC = FA_KT * CH / (FA_NW * 64), LDK = DK + 8;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const int c = tid + k * FA_NW * 64, j = c / CH, dc = c % CH;
+        if (ROWS) *(bf16x8 *)&rows[j * LDK + dc * 8] = f.v[k];
+        if (COLS) {
+            const int col = (j & ~15) + kperm16(j & 15);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cols[(dc * 8 + e) * FA_LDT + col] = (unsigned short)f.v[k][e];
+        }
+    }
+}
 // 32x32 tile: sum_s A[(row0 + r)][16 s + 8 h ..] x B[s]   (A from a row-major LDS image with stride DK+8)
 template <int DK>
 __device__ __forceinline__ f32x16 fa_mm_rows(const unsigned short *img, int row0, int r, int h, const bf16x8 (&B)[DK / 16]) {

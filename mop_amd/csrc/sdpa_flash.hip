@@ -65,7 +65,7 @@ __device__ __forceinline__ float fa_apply_mb(float z, const FaMB &m, const MopkS
 
 // ------------------------------------------------------------------ forward
 template <int DK, typename IOT, bool CAUSAL, bool DUAL, bool MB>
-__global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_fwd_kernel(MopkSdpaArgs a, float *lse, FaDual u) {
+__global__ void __launch_bounds__(FA_NW * 64, DUAL ? 2 : 3) sdpa_flash_fwd_kernel(MopkSdpaArgs a, float *lse, FaDual u) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vt[DK * FA_LDT], K2s[DUAL ? FA_KT * LDK : 8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -92,12 +92,21 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_fwd_kernel(MopkSdpaArgs
     for (int dt = 0; dt < DT; ++dt) O[dt] = fa_zero();
     int nkt = (N + FA_KT - 1) / FA_KT;
     if (CAUSAL) nkt = min(nkt, (min(q0 + FA_QB, N) + FA_KT - 1) / FA_KT);   // keys beyond the block's last query are never seen
+    FaTile<DK> fk, fv, fk2;               // next tile's K / V (/ K2) rows, in flight while the current tile is computed
+    fa_fetch<DK, IOT>(fk, kp, a.k.sn, 0, N, 1.f, tid);
+    fa_fetch<DK, IOT>(fv, vp, a.v.sn, 0, N, 1.f, tid);
+    if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, u.k2.sn, 0, N, 1.f, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * FA_KT;
         __syncthreads();
-        fa_stage<DK, IOT, true, false>(Ks, nullptr, kp, a.k.sn, k0, N, 1.f, tid);
-        fa_stage<DK, IOT, false, true>(nullptr, Vt, vp, a.v.sn, k0, N, 1.f, tid);
-        if (DUAL) fa_stage<DK, IOT, true, false>(K2s, nullptr, k2p, u.k2.sn, k0, N, 1.f, tid);
+        fa_put<DK, true, false>(Ks, nullptr, fk, tid);
+        fa_put<DK, false, true>(nullptr, Vt, fv, tid);
+        if (DUAL) fa_put<DK, true, false>(K2s, nullptr, fk2, tid);
+        if (kt + 1 < nkt) {
+            fa_fetch<DK, IOT>(fk, kp, a.k.sn, k0 + FA_KT, N, 1.f, tid);
+            fa_fetch<DK, IOT>(fv, vp, a.v.sn, k0 + FA_KT, N, 1.f, tid);
+            if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, u.k2.sn, k0 + FA_KT, N, 1.f, tid);
+        }
         __syncthreads();
         f32x16 S[2];
         float mx = FA_NEG;
