@@ -204,12 +204,21 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
     for (int dt = 0; dt < DT; ++dt) { dQ[dt] = fa_zero(); if (DUAL) dQ2[dt] = fa_zero(); }
     int nkt = (N + FA_KT - 1) / FA_KT;
     if (CAUSAL) nkt = min(nkt, (min(q0 + FA_QB, N) + FA_KT - 1) / FA_KT);
+    FaTile<DK> fk, fv, fk2;
+    fa_fetch<DK, IOT>(fk, kp, a.k.sn, 0, N, 1.f, tid);
+    fa_fetch<DK, IOT>(fv, vp, a.v.sn, 0, N, 1.f, tid);
+    if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, u.k2.sn, 0, N, 1.f, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * FA_KT;
         __syncthreads();
-        fa_stage<DK, IOT, true, true>(Ks, Kt, kp, a.k.sn, k0, N, 1.f, tid);
-        fa_stage<DK, IOT, true, false>(Vs, nullptr, vp, a.v.sn, k0, N, 1.f, tid);
-        if (DUAL) fa_stage<DK, IOT, true, true>(K2s, K2t, k2p, u.k2.sn, k0, N, 1.f, tid);
+        fa_put<DK, true, true>(Ks, Kt, fk, tid);
+        fa_put<DK, true, false>(Vs, nullptr, fv, tid);
+        if (DUAL) fa_put<DK, true, true>(K2s, K2t, fk2, tid);
+        if (kt + 1 < nkt) {
+            fa_fetch<DK, IOT>(fk, kp, a.k.sn, k0 + FA_KT, N, 1.f, tid);
+            fa_fetch<DK, IOT>(fv, vp, a.v.sn, k0 + FA_KT, N, 1.f, tid);
+            if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, u.k2.sn, k0 + FA_KT, N, 1.f, tid);
+        }
         __syncthreads();
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -270,13 +279,22 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dK[dt] = fa_zero(); dV[dt] = fa_zero(); if (DUAL) dK2[dt] = fa_zero(); }
     const FaMB mb = fa_mb(a, b, hh);
-    const int nqt = (N + FA_KT - 1) / FA_KT;
-    for (int qt = CAUSAL ? k0 / FA_KT : 0; qt < nqt; ++qt) {      // causal: queries before this key block see none of its keys
+    const int nqt = (N + FA_KT - 1) / FA_KT, qt0 = CAUSAL ? k0 / FA_KT : 0;   // causal: queries before this key block see none of its keys
+    FaTile<DK> fq, fg, fq2;               // q is pre-scaled exactly as the forward's fragments
+    fa_fetch<DK, IOT>(fq, qp, a.q.sn, qt0 * FA_KT, N, c, tid);
+    fa_fetch<DK, IOT>(fg, gp, a.dy.sn, qt0 * FA_KT, N, 1.f, tid);
+    if (DUAL) fa_fetch<DK, IOT>(fq2, q2p, u.q2.sn, qt0 * FA_KT, N, c, tid);
+    for (int qt = qt0; qt < nqt; ++qt) {
         const int i0 = qt * FA_KT;
         __syncthreads();
-        fa_stage<DK, IOT, true, true>(Qs, Qt, qp, a.q.sn, i0, N, c, tid);       // q pre-scaled exactly as the forward's fragments
-        fa_stage<DK, IOT, true, true>(Gs, Gt, gp, a.dy.sn, i0, N, 1.f, tid);
-        if (DUAL) fa_stage<DK, IOT, true, true>(Q2s, Q2t, q2p, u.q2.sn, i0, N, c, tid);
+        fa_put<DK, true, true>(Qs, Qt, fq, tid);
+        fa_put<DK, true, true>(Gs, Gt, fg, tid);
+        if (DUAL) fa_put<DK, true, true>(Q2s, Q2t, fq2, tid);
+        if (qt + 1 < nqt) {
+            fa_fetch<DK, IOT>(fq, qp, a.q.sn, i0 + FA_KT, N, c, tid);
+            fa_fetch<DK, IOT>(fg, gp, a.dy.sn, i0 + FA_KT, N, 1.f, tid);
+            if (DUAL) fa_fetch<DK, IOT>(fq2, q2p, u.q2.sn, i0 + FA_KT, N, c, tid);
+        }
         if (tid < FA_KT) {
             const bool ok = i0 + tid < N;
             Ls[tid] = ok ? lse[(int64_t)bh * N + i0 + tid] : 0.f;
