@@ -70,11 +70,18 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_stats_kernel(MopkQuartetArgs a,
     }
     float pv1 = 0.f, pv2 = 0.f, s1 = 0.f, ss1 = 0.f, s2 = 0.f, ss2 = 0.f;   // sums of (S - pivot), pivot = S[i, 0]: no cancellation
     const int nkt = (N + FA_KT - 1) / FA_KT;
+    FaTile<DK> fk, fk2;
+    fa_fetch<DK, IOT>(fk, kp, a.k.sn, 0, N, 1.f, tid);
+    if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, a.k2.sn, 0, N, 1.f, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * FA_KT;
         __syncthreads();
-        fa_stage<DK, IOT, true, false>(Ks, nullptr, kp, a.k.sn, k0, N, 1.f, tid);
-        if (DUAL) fa_stage<DK, IOT, true, false>(K2s, nullptr, k2p, a.k2.sn, k0, N, 1.f, tid);
+        fa_put<DK, true, false>(Ks, nullptr, fk, tid);
+        if (DUAL) fa_put<DK, true, false>(K2s, nullptr, fk2, tid);
+        if (kt + 1 < nkt) {
+            fa_fetch<DK, IOT>(fk, kp, a.k.sn, k0 + FA_KT, N, 1.f, tid);
+            if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, a.k2.sn, k0 + FA_KT, N, 1.f, tid);
+        }
         __syncthreads();
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -130,12 +137,21 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, c
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) O[dt] = fa_zero();
     const int nkt = min((N + FA_KT - 1) / FA_KT, (min(q0 + FA_QB, N) + FA_KT - 1) / FA_KT);      // causal   :112-113
+    FaTile<DK> fk, fv, fk2;
+    fa_fetch<DK, IOT>(fk, kp, a.k.sn, 0, N, 1.f, tid);
+    fa_fetch<DK, IOT>(fv, vp, a.v.sn, 0, N, 1.f, tid);
+    if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, a.k2.sn, 0, N, 1.f, tid);
     for (int kt = 0; kt < nkt; ++kt) {
         const int k0 = kt * FA_KT;
         __syncthreads();
-        fa_stage<DK, IOT, true, false>(Ks, nullptr, kp, a.k.sn, k0, N, 1.f, tid);
-        fa_stage<DK, IOT, false, true>(nullptr, Vt, vp, a.v.sn, k0, N, 1.f, tid);
-        if (DUAL) fa_stage<DK, IOT, true, false>(K2s, nullptr, k2p, a.k2.sn, k0, N, 1.f, tid);
+        fa_put<DK, true, false>(Ks, nullptr, fk, tid);
+        fa_put<DK, false, true>(nullptr, Vt, fv, tid);
+        if (DUAL) fa_put<DK, true, false>(K2s, nullptr, fk2, tid);
+        if (kt + 1 < nkt) {
+            fa_fetch<DK, IOT>(fk, kp, a.k.sn, k0 + FA_KT, N, 1.f, tid);
+            fa_fetch<DK, IOT>(fv, vp, a.v.sn, k0 + FA_KT, N, 1.f, tid);
+            if (DUAL) fa_fetch<DK, IOT>(fk2, k2p, a.k2.sn, k0 + FA_KT, N, 1.f, tid);
+        }
         __syncthreads();
         f32x16 S[2];
         float mx = FA_NEG;
