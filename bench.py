@@ -19,6 +19,13 @@ import os
 import sys
 import time
 
+# the qkv / proj Linear layers are hipBLASLt GEMMs (PyTorch plumbing, 9 % of the step): let PyTorch's TunableOp pick their
+# kernels during the untimed warm-up (-2 % step time; opt out with MOPK_BENCH_TUNABLEOP=0)
+if os.environ.get("MOPK_BENCH_TUNABLEOP", "1") != "0":
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", "/tmp/mopk_bench_tunableop_%d.csv")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

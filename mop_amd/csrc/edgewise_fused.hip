@@ -18,6 +18,8 @@
 //     splits of a and b packed into the K=16 slots, i.e. ~fp32-accurate.
 //
 // HBM traffic per (b,h): q,k,v in + y out (~100 KB) for 0.9 GFLOP -> MFMA/VALU bound.
+#include <stdlib.h>
+
 #include "fused_common.h"
 
 #ifdef MOPK_WHATIF_NOBAR       // timing experiment only (results are wrong)
@@ -667,8 +669,14 @@ size_t ew_fused_saved_bytes(const MopkEdgewiseArgs *a) {
     switch (pick_nt(a->N)) { case 1: MOPK_DKS(1) case 2: MOPK_DKS(2) case 4: MOPK_DKS(4) case 7: MOPK_DKS(7) default: return 0; }
 #undef MOPK_DKS
 }
+int ew16_fwd_supported(const MopkEdgewiseArgs *a);
+int ew16_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
+// MOPK_EW16=1 (read per call) routes the shapes it covers to the 16-query-wave forward instead: an experiment kept for A/B
+// timing -- at the bench shape it is 12 % slower than the 32-query kernel, so it is off by default
+static bool ew16_enabled() { const char *e = getenv("MOPK_EW16"); return e && e[0] == '1'; }
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     if (!ew_fused_fwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
+    if (ew16_enabled() && ew16_fwd_supported(a)) return ew16_fwd(a, st);     // same `saved` record, 16-query waves (edgewise_fused16.hip)
 #define MOPK_DK(NT_)                                                         \
     switch (a->dk) {                                                         \
         case 16: return ew_fused_fwd_nt##NT_##_dk16(a, st);                  \

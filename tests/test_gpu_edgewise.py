@@ -211,6 +211,35 @@ def test_fused_vs_oracle_shape_sweep(shape):
     check_grads(grads, g_ref, GTOL_BF16, scalar_tol=0.5, floor=2e-3)
 
 
+@pytest.mark.parametrize("shape", [(1, 129, 128, 2, 3, 1), (2, 197, 128, 2, 5, 4), (1, 224, 64, 1, 5, 4), (2, 150, 64, 2, 4, 2)])
+def test_forward_with_16_query_waves_matches_the_default_kernel_and_feeds_the_backward(shape, monkeypatch):
+    """MOPK_EW16=1 swaps in the 16-query-wave forward (edgewise_fused16.hip) for 128 < N <= 224, dk 32/64: its output must
+    match the oracle like the default kernel's, and the chain state it exports must drive the (32-query) backward to the
+    same gradients."""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd import ops, _lib
+    B, N, D, H, V, r = shape
+    mop_amd.set_precision("bf16")
+    m = _mk(D, H, V, r, seed=B * 1000 + N)
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, N, D, generator=g).numpy()
+    w = torch.randn(B, N, D, generator=g).numpy()
+    out, cache = oe.module_fwd(x.astype(np.float64), params, H, V, True, 0.5)
+    dx_ref, g_ref = oe.module_bwd(w.astype(np.float64), cache)
+    m = m.cuda().eval()
+    y0, dx0, grads0 = run_fwd_bwd(m, x, w)
+    monkeypatch.setenv("MOPK_EW16", "1")
+    m.zero_grad(set_to_none=True)
+    y1, dx1, grads1 = run_fwd_bwd(m, x, w)
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED
+    assert max_abs(y1, out) <= TOL_BF16
+    assert max_abs(y1, y0) <= 4e-3            # two bf16 evaluation orders of the same maps
+    assert rel_err(dx1, dx_ref) <= 5e-2
+    check_grads(grads1, g_ref, GTOL_BF16, scalar_tol=0.5, floor=2e-3)
+
+
 def test_shapes_outside_the_fused_kernels_take_the_generic_path():
     import mop_amd
     from mop_amd import ops, _lib
