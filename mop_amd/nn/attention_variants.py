@@ -28,6 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .linear import TokenLinear
 
 # gate order inside the low-rank head: 0=and 1=or 2=not 3=chain   (:284)
 _LOWRANK_PRESET = {
@@ -125,14 +126,14 @@ class EdgewiseMSA(nn.Module):
             raise ValueError("use_lens_bank_qk=True requires share_qkv=True for now")
         V, H, dk = self.n_views, self.h, self.dk
         if self.share_qkv:
-            self.qkv = nn.Linear(dim, 3 * dim, bias=False)
+            self.qkv = TokenLinear(dim, 3 * dim, bias=False)
             self.q_scale = nn.Parameter(torch.ones(V, H, 1, dk))
             self.k_scale = nn.Parameter(torch.ones(V, H, 1, dk))
             self.v_scale = nn.Parameter(torch.ones(V, H, 1, dk))
         else:
-            self.qkv_list = nn.ModuleList(nn.Linear(dim, 3 * dim, bias=False) for _ in range(V))
+            self.qkv_list = nn.ModuleList(TokenLinear(dim, 3 * dim, bias=False) for _ in range(V))
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj = TokenLinear(dim, dim, bias=False)
         self.proj_drop = nn.Dropout(proj_drop)
         num_s = len(self.lens_qk_dilations) if self.use_lens_bank_qk else V
         in_ch = 2 * num_s + 2
@@ -233,9 +234,9 @@ class BaselineMSA(nn.Module):
         super().__init__()
         assert dim % heads == 0
         self.h, self.dk = heads, dim // heads
-        self.qkv = nn.Linear(dim, 3 * dim, bias=False)
+        self.qkv = TokenLinear(dim, 3 * dim, bias=False)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj = TokenLinear(dim, dim, bias=False)
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -255,10 +256,10 @@ class MultiHopMSA(nn.Module):
         assert dim % heads == 0
         assert hops >= 2
         self.h, self.dk, self.hops = heads, dim // heads, int(hops)
-        self.qkv1 = nn.Linear(dim, 3 * dim, bias=False)
-        self.qkv2 = nn.Linear(dim, 3 * dim, bias=False)
+        self.qkv1 = TokenLinear(dim, 3 * dim, bias=False)
+        self.qkv2 = TokenLinear(dim, 3 * dim, bias=False)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj = TokenLinear(dim, dim, bias=False)
         self.proj_drop = nn.Dropout(proj_drop)
         self.beta_not = float(beta_not)
         self.gates = gates or dict(and_=1.0, or_=0.0, not_=0.0, chain=0.0, base=1.0)
@@ -287,10 +288,10 @@ class CrossViewMixerMSA(nn.Module):
         super().__init__()
         assert dim % heads == 0
         self.h, self.dk = heads, dim // heads
-        self.qkv1 = nn.Linear(dim, 3 * dim, bias=False)
-        self.qkv2 = nn.Linear(dim, 3 * dim, bias=False)
+        self.qkv1 = TokenLinear(dim, 3 * dim, bias=False)
+        self.qkv2 = TokenLinear(dim, 3 * dim, bias=False)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj = TokenLinear(dim, dim, bias=False)
         self.proj_drop = nn.Dropout(proj_drop)
         self.mix = nn.Parameter(torch.eye(2))
         self.use_transpose_cues, self.t1, self.t2 = bool(use_transpose_cues), float(t1), float(t2)

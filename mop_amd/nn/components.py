@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .linear import TokenLinear
 
 
 class DropPath(nn.Module):
@@ -44,9 +45,9 @@ class MSA(nn.Module):
         super().__init__()
         assert dim % heads == 0
         self.h, self.dk = heads, dim // heads
-        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.qkv = TokenLinear(dim, dim * 3, bias=False)
         self.attn_drop = nn.Dropout(attn_drop)
-        self.proj = nn.Linear(dim, dim, bias=False)
+        self.proj = TokenLinear(dim, dim, bias=False)
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x):
@@ -62,8 +63,8 @@ class MLP(nn.Module):
     def __init__(self, dim, mlp_ratio=4.0, drop=0.0):
         super().__init__()
         hid = int(dim * mlp_ratio)
-        self.fc1 = nn.Linear(dim, hid, bias=False)
-        self.fc2 = nn.Linear(hid, dim, bias=False)
+        self.fc1 = TokenLinear(dim, hid, bias=False)
+        self.fc2 = TokenLinear(hid, dim, bias=False)
         self.act = nn.GELU(approximate="tanh")
         self.drop = nn.Dropout(drop)
 
@@ -107,7 +108,7 @@ class ViTEncoder(nn.Module):
 class ViewsLinear(nn.Module):
     def __init__(self, dim, n_views=5):
         super().__init__()
-        self.proj = nn.Linear(dim, n_views, bias=False)
+        self.proj = TokenLinear(dim, n_views, bias=False)
         self.n_views = n_views
 
     def forward(self, tok, grid):

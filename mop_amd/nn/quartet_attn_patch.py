@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .linear import TokenLinear
 
 
 @dataclass
@@ -39,13 +40,13 @@ class CausalSelfAttention(nn.Module):
         self.head_dim = config.n_embd // config.n_head
         self.scale = 1.0 / math.sqrt(self.head_dim)
         C = config.n_embd
-        self.q_proj = nn.Linear(C, C, bias=config.bias)
-        self.k_proj = nn.Linear(C, C, bias=config.bias)
-        self.v_proj = nn.Linear(C, C, bias=config.bias)
-        self.o_proj = nn.Linear(C, C, bias=config.bias)
+        self.q_proj = TokenLinear(C, C, bias=config.bias)
+        self.k_proj = TokenLinear(C, C, bias=config.bias)
+        self.v_proj = TokenLinear(C, C, bias=config.bias)
+        self.o_proj = TokenLinear(C, C, bias=config.bias)
         if config.use_quartet:
-            self.q2_proj = nn.Linear(C, C, bias=config.bias)
-            self.k2_proj = nn.Linear(C, C, bias=config.bias)
+            self.q2_proj = TokenLinear(C, C, bias=config.bias)
+            self.k2_proj = TokenLinear(C, C, bias=config.bias)
             self.mixture = nn.Parameter(torch.tensor([config.quartet_gate_init], dtype=torch.float32))
             self.quartet_scale = nn.Parameter(torch.tensor([config.quartet_scale], dtype=torch.float32))
         else:

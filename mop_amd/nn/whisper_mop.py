@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .linear import TokenLinear
 
 
 @dataclass
@@ -90,10 +91,10 @@ class MultiheadSelfAttention(nn.Module):
         assert dim % n_head == 0
         self.dim, self.n_head, self.head_dim, self.causal = dim, n_head, dim // n_head, causal
         self.scale = self.head_dim ** -0.5
-        self.q_proj = nn.Linear(dim, dim, bias=bias)
-        self.k_proj = nn.Linear(dim, dim, bias=bias)
-        self.v_proj = nn.Linear(dim, dim, bias=bias)
-        self.o_proj = nn.Linear(dim, dim, bias=bias)
+        self.q_proj = TokenLinear(dim, dim, bias=bias)
+        self.k_proj = TokenLinear(dim, dim, bias=bias)
+        self.v_proj = TokenLinear(dim, dim, bias=bias)
+        self.o_proj = TokenLinear(dim, dim, bias=bias)
         self.attn_drop = nn.Dropout(dropout)
         self.resid_drop = nn.Dropout(dropout)
 
@@ -110,8 +111,8 @@ class MultiheadSelfAttention(nn.Module):
 class MLP(nn.Module):
     def __init__(self, dim: int, dropout: float, bias: bool):
         super().__init__()
-        self.fc = nn.Linear(dim, 4 * dim, bias=bias)
-        self.proj = nn.Linear(4 * dim, dim, bias=bias)
+        self.fc = TokenLinear(dim, 4 * dim, bias=bias)
+        self.proj = TokenLinear(4 * dim, dim, bias=bias)
         self.drop = nn.Dropout(dropout)
 
     def forward(self, x):

@@ -154,3 +154,26 @@ def test_vit_edgewise_state_dict_layout_and_checkpoint_roundtrip(tmp_path):
     ck = load_checkpoint(m2, None, path)
     assert ck["epoch"] == 3 and set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_token_linear_matches_nn_linear_forward_and_gradients():
+    """TokenLinear = nn.Linear (same keys, same forward); its weight gradient is a batched GEMM over row slices summed in fp32."""
+    import torch.nn as nn
+    from mop_amd.nn.linear import TokenLinear, _TokenLinearFn, weight_grad_splits
+    assert weight_grad_splits(256 * 197, 1152) == 16 and weight_grad_splits(256 * 197, 384) == 32
+    assert weight_grad_splits(1000, 384) == 1 and weight_grad_splits(4097, 384) == 1 and weight_grad_splits(197 * 64, 64) == 32
+    torch.manual_seed(0)
+    ref, lin = nn.Linear(48, 64, bias=True), TokenLinear(48, 64, bias=True)
+    lin.load_state_dict(ref.state_dict())
+    assert set(lin.state_dict()) == {"weight", "bias"} and isinstance(lin, nn.Linear)
+    x = torch.randn(8, 1024, 48, requires_grad=True)           # 8192 rows -> 16 slices... (cap 32: 8192 = 2^13 -> 32)
+    x2 = x.detach().clone().requires_grad_(True)
+    w = torch.randn(8, 1024, 64)
+    (ref(x) * w).sum().backward()
+    y = _TokenLinearFn.apply(x2, lin.weight, lin.bias)         # the CUDA forward path, exercised on the CPU
+    (y * w).sum().backward()
+    assert torch.equal(y, ref(x2))
+    assert torch.allclose(x2.grad, x.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-4)
+    assert torch.equal(lin(x2), ref(x2))                       # CPU tensors take the plain F.linear branch
