@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 110 /* 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd */
+#define MOPK_VERSION 111 /* 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -267,6 +267,13 @@ size_t mopk_crossview_saved_bytes(const MopkCrossViewArgs *a);
 size_t mopk_crossview_workspace_bytes(const MopkCrossViewArgs *a);
 int mopk_crossview_fwd(const MopkCrossViewArgs *a, void *stream);
 int mopk_crossview_bwd(const MopkCrossViewArgs *a, void *stream);
+
+/* Sum the per-batch partial gradients an Edgewise backward left in a->dsqk_part (B,V,H,dk), a->dvs0_part, a->dvsL_part
+ * (B,H,dk) and a->dlogit_part (B,H) over the batch, in a fixed order (bitwise reproducible), into dsqk (V,H,dk), dvs0, dvsL
+ * (H,dk) and dlogit (1): one launch in place of the four reductions `q_scale.grad`, `v_scale.grad` and
+ * `chain_value_logit.grad` would otherwise need on the host side (attention_variants.py:374-378, :451 are the parameters).
+ * Reads only B, V, H, dk and the four *_part pointers of `a`. */
+int mopk_edgewise_reduce_parts(const MopkEdgewiseArgs *a, float *dsqk, float *dvs0, float *dvsL, float *dlogit, void *stream);
 
 /* -------------------------------------------------------------------------- */
 int mopk_version(void);

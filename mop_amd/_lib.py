@@ -117,6 +117,7 @@ SYMBOLS = {
     "mopk_edgewise_workspace_bytes": (C.c_size_t, [C.POINTER(EdgewiseArgs)]),
     "mopk_edgewise_lowrank_fwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
     "mopk_edgewise_lowrank_bwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
+    "mopk_edgewise_reduce_parts": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mopk_edgewise_fwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
     "mopk_edgewise_bwd": (C.c_int, [C.POINTER(EdgewiseArgs), C.c_void_p]),
     "mopk_dualpath_saved_bytes": (C.c_size_t, [C.POINTER(DualPathArgs)]),

@@ -6,6 +6,7 @@ size_t ew_generic_saved_bytes(const MopkEdgewiseArgs *a);
 size_t ew_generic_workspace_bytes(const MopkEdgewiseArgs *a);
 int ew_generic_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 int ew_generic_bwd(const MopkEdgewiseArgs *a, hipStream_t st);
+int ew_reduce_parts(const MopkEdgewiseArgs *a, float *dsqk, float *dvs0, float *dvsL, float *dlogit, hipStream_t st);
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 size_t ew_fused_saved_bytes(const MopkEdgewiseArgs *a);
@@ -108,6 +109,12 @@ int mopk_edgewise_bwd(const MopkEdgewiseArgs *a, void *stream) {
 int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {
     if (a && a->ext && a->ext->gate_mode != 0) return MOPK_ERR_BAD_ARG;
     return mopk_edgewise_fwd(a, stream);
+}
+int mopk_edgewise_reduce_parts(const MopkEdgewiseArgs *a, float *dsqk, float *dvs0, float *dvsL, float *dlogit, void *stream) {
+    if (!a || !dsqk || !dvs0 || !dvsL || !dlogit || !a->dsqk_part || !a->dvs0_part || !a->dvsL_part || !a->dlogit_part)
+        return MOPK_ERR_BAD_ARG;
+    if (a->B <= 0 || a->H <= 0 || a->V <= 0 || a->dk <= 0) return MOPK_ERR_BAD_SHAPE;
+    return ew_reduce_parts(a, dsqk, dvs0, dvsL, dlogit, (hipStream_t)stream);
 }
 int mopk_edgewise_lowrank_bwd(const MopkEdgewiseArgs *a, void *stream) {
     if (a && a->ext && a->ext->gate_mode != 0) return MOPK_ERR_BAD_ARG;

@@ -1026,6 +1026,51 @@ static int ew_generic_bwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
     return MOPK_OK;
 }
 
+// ---- batch reduction of the small per-(b) partial gradients: 16 outputs x 16 batch slices per block, slices combined in a
+// fixed order; the last block sums dlogit_part
+__global__ void __launch_bounds__(256) ew_reduce_parts_kernel(const float *dsqk_p, const float *dvs0_p, const float *dvsL_p,
+                                                             const float *dlg_p, float *dsqk, float *dvs0, float *dvsL,
+                                                             float *dlogit, int B, int n_sqk, int n_vs, int n_lg) {
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {
+        float s = 0.f;
+        for (int i = tid; i < n_lg; i += 256) s += dlg_p[i];
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        if (tid == 0) *dlogit = red[0];
+        return;
+    }
+    const int o = blockIdx.x * 16 + (tid & 15), sl = tid >> 4, total = n_sqk + 2 * n_vs;
+    float s = 0.f;
+    if (o < total) {
+        const float *src; int w, c;
+        if (o < n_sqk) { src = dsqk_p; w = n_sqk; c = o; }
+        else if (o < n_sqk + n_vs) { src = dvs0_p; w = n_vs; c = o - n_sqk; }
+        else { src = dvsL_p; w = n_vs; c = o - n_sqk - n_vs; }
+#pragma unroll 4
+        for (int b = sl; b < B; b += 16) s += src[(size_t)b * w + c];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (sl == 0 && o < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k * 16 + tid];
+        if (o < n_sqk) dsqk[o] = t;
+        else if (o < n_sqk + n_vs) dvs0[o - n_sqk] = t;
+        else dvsL[o - n_sqk - n_vs] = t;
+    }
+}
+int ew_reduce_parts(const MopkEdgewiseArgs *a, float *dsqk, float *dvs0, float *dvsL, float *dlogit, hipStream_t st) {
+    const int n_sqk = a->V * a->H * a->dk, n_vs = a->H * a->dk, total = n_sqk + 2 * n_vs;
+    hipLaunchKernelGGL(ew_reduce_parts_kernel, dim3((total + 15) / 16 + 1), dim3(256), 0, st, a->dsqk_part, a->dvs0_part,
+                       a->dvsL_part, a->dlogit_part, dsqk, dvs0, dvsL, dlogit, a->B, n_sqk, n_vs, a->B * a->H);
+    MOPK_CHECK_LAUNCH();
+    return MOPK_OK;
+}
+
 int ew_generic_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     return a->io_dtype == MOPK_BF16 ? ew_generic_fwd_t<unsigned short>(a, st) : ew_generic_fwd_t<float>(a, st);
 }

@@ -71,6 +71,21 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+def _f32_pack(ts):
+    """fp32 contiguous copies of several small parameter tensors.  fp32 inputs are used as they are; otherwise ONE
+    concatenation + ONE conversion kernel serve all of them (views of a single buffer) instead of one cast kernel each."""
+    if all(t.dtype == torch.float32 for t in ts):
+        return [t.detach().contiguous() for t in ts]
+    if len({t.dtype for t in ts}) != 1:
+        return [_f32c(t) for t in ts]
+    flat = torch.cat([t.detach().reshape(-1) for t in ts]).to(torch.float32)
+    out, o = [], 0
+    for t in ts:
+        out.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
+    return out
+
+
 # ---- optional kernel timing (bench.py): HIP events on the stream the kernels are launched on ----
 LAST_PATH = {}  # entry point -> MopkPath actually requested on the last call (tests assert on it)
 _TIMING = None  # dict name -> list[(start_event, stop_event)] when enabled
@@ -149,8 +164,9 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         B, N, Vq, _, H, dk = qkv.shape
         qkv = qkv.contiguous()
         dev = qkv.device
-        f = dict(sqk=_f32c(sqk), vs0=_f32c(vs0), vsL=_f32c(vsL), Wr=_f32c(Wr), br=_f32c(br),
-                 Wc=_f32c(Wc), bc=_f32c(bc), logit=_f32c(logit).reshape(1))
+        f = dict(zip(("sqk", "vs0", "vsL", "Wr", "br", "Wc", "bc", "logit"),
+                     _f32_pack([sqk, vs0, vsL, Wr, br, Wc, bc, logit.reshape(1)])))
+        ctx.small_dtype = sqk.dtype if len({t.dtype for t in (sqk, vs0, vsL, Wr, br, Wc, bc, logit)}) == 1 else None
         r = f["Wr"].shape[0] // 4
         a = L.EdgewiseArgs()
         a.B, a.H, a.N, a.dk, a.V, a.r = B, H, N, dk, V, r
@@ -203,18 +219,17 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         dqkv = (torch.empty_like(qkv) if Vq == 1 else torch.zeros_like(qkv))
         _ew_views(a, dqkv, "d")
         f32 = dict(dtype=torch.float32, device=dev)
-        dsqk = torch.empty(B, V, H, dk, **f32)
-        dvs0 = torch.empty(B, H, dk, **f32)
-        dvsL = torch.empty(B, H, dk, **f32)
         C_ = 2 * V + 2
-        dWr = torch.empty(4 * r, C_, **f32)
-        dWc = torch.empty(4 * r, C_, **f32)
-        dbr = torch.empty(4 * r, **f32)
-        dbc = torch.empty(4 * r, **f32)
-        dlg = torch.empty(B, H, **f32)
-        a.dsqk_part, a.dvs0_part, a.dvsL_part = dsqk.data_ptr(), dvs0.data_ptr(), dvsL.data_ptr()
+        # per-batch partials of the small gradients, and ONE buffer for their final values (reduced by the library in a single
+        # launch, cast to the parameters' dtype in a single kernel, handed to autograd as views)
+        n_sqk, n_vs, n_w, n_b = V * H * dk, H * dk, 4 * r * C_, 4 * r
+        parts = torch.empty(B * (n_sqk + 2 * n_vs + H), **f32)
+        dsqk_p, dvs0_p, dvsL_p, dlg_p = torch.split(parts, [B * n_sqk, B * n_vs, B * n_vs, B * H])
+        small = torch.empty(n_sqk + 2 * n_vs + 2 * n_w + 2 * n_b + 1, **f32)
+        dsqk, dvs0, dvsL, dWr, dbr, dWc, dbc, dlg = torch.split(small, [n_sqk, n_vs, n_vs, n_w, n_b, n_w, n_b, 1])
+        a.dsqk_part, a.dvs0_part, a.dvsL_part = dsqk_p.data_ptr(), dvs0_p.data_ptr(), dvsL_p.data_ptr()
         a.dWr, a.dbr, a.dWc, a.dbc = dWr.data_ptr(), dbr.data_ptr(), dWc.data_ptr(), dbc.data_ptr()
-        a.dlogit_part = dlg.data_ptr()
+        a.dlogit_part = dlg_p.data_ptr()
         LAST_PATH["edgewise_bwd"] = path
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         LAST_PATH["_bwd_ws"] = ws  # kept for diagnostics (stamp builds read it back)
@@ -222,8 +237,13 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         with _timed("edgewise_bwd"):
             rc = lib.mopk_edgewise_lowrank_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_lowrank_bwd")
-        return (dqkv, dsqk.sum(0), dvs0.sum(0), dvsL.sum(0), dWr, dbr, dWc, dbc,
-                dlg.sum().reshape(()), None, None, None, None, None)
+        L.check(lib.mopk_edgewise_reduce_parts(C.byref(a), dsqk.data_ptr(), dvs0.data_ptr(), dvsL.data_ptr(), dlg.data_ptr(),
+                                               _stream()), "mopk_edgewise_reduce_parts")
+        if ctx.small_dtype is not None and ctx.small_dtype != torch.float32:
+            small = small.to(ctx.small_dtype)
+            dsqk, dvs0, dvsL, dWr, dbr, dWc, dbc, dlg = torch.split(small, [n_sqk, n_vs, n_vs, n_w, n_b, n_w, n_b, 1])
+        return (dqkv, dsqk.view(V, H, dk), dvs0.view(H, dk), dvsL.view(H, dk), dWr.view(4 * r, C_), dbr, dWc.view(4 * r, C_), dbc,
+                dlg.reshape(()), None, None, None, None, None)
 
 
 class EdgewiseVariant:
