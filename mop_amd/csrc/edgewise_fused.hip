@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
             constexpr int CH = DK / 8;
             for (int c = tid; c < NP * CH; c += NT * 64) {
-                const int j = c / CH, dc = c % CH;
+                const int j = c % NP, dc = c / NP;     // consecutive lanes = consecutive keys: conflict-free 2-byte transposing stores
                 bf16x8 x0 = {0, 0, 0, 0, 0, 0, 0, 0}, xL = x0;
                 if (j < N) { x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8); xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8); }
                 const int col = (j & ~15) + kperm16(j & 15);
