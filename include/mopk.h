@@ -106,8 +106,9 @@ typedef struct MopkEdgewiseArgs {
     int32_t precision;  /* MopkPrecision                           */
     int32_t path;       /* MopkPath                                */
     int32_t save_for_backward; /* fused path: 1 = fwd also exports the chain state (prefix products, softmax constants,
-                                * log-means) into `saved` and _bwd reads it instead of recomputing; must have the same
-                                * value in the fwd call, the bwd call and both *_bytes() queries.  0 = small `saved`. */
+                                * log-means) and the mix state (mixed logits, view log-sum-exp, softmax row statistics,
+                                * P v0) into `saved`, and _bwd reads them instead of recomputing.  Must have the same value in
+                                * the fwd call, the bwd call and both *_bytes() queries.  0 = small `saved`, _bwd recomputes. */
     float beta_not;     /* :361, used at :546 */
 
     MopkView5 q, k;          /* per-view (sv!=0) or shared (sv==0) queries / keys  :461-470 */

@@ -526,6 +526,17 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int g = 0; g < 16; ++g) L[g] = mx[g] + __logf(se[g]);   // lse_v S_v - S_0
         }
+        if (SAVE) {                       // L x log2(e) as packed fp16, accumulator order (the backward's S_L slab)
+            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+            u4 lo, hi;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                lo[p] = pack_h2(L[2 * p] * 1.4426950408889634f, L[2 * p + 1] * 1.4426950408889634f);
+                hi[p] = pack_h2(L[8 + 2 * p] * 1.4426950408889634f, L[8 + 2 * p + 1] * 1.4426950408889634f);
+            }
+            u4 *lp = (u4 *)(svb + SL.oL + (size_t)w * NT * 8 * 64 * 4) + lane;
+            lp[(2 * t) * 64] = lo; lp[(2 * t + 1) * 64] = hi;
+        }
         // Smix = S0 + (G_and - nb G_not) O + G_or L + G_chain Cr, one gate at a time
         {
             const f32x16 G = gate_tile(t, 0);
@@ -553,6 +564,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 mxrow = fmaxf(mxrow, fmaxf(s0, s1));
                 cw[p] = pack_h2(s0, s1);
             }
+            if (SAVE) {                   // Smix as packed fp16 (the backward's S_SM slab)
+                typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+                u4 *sp = (u4 *)(svb + SL.oSm + (size_t)w * NT * 8 * 64 * 4) + lane;
+                sp[(2 * t) * 64] = u4{cw[0], cw[1], cw[2], cw[3]};
+                sp[(2 * t + 1) * 64] = u4{cw[4], cw[5], cw[6], cw[7]};
+            }
         }
         switch (t) {
 #define MOPK_CASE(T_) case T_: if (T_ < NT) { _Pragma("unroll") for (int p = 0; p < 8; ++p) crp[T_ < NT ? T_ : 0][p] = cw[p]; } break;
@@ -578,6 +595,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
     l += __shfl_xor(l, 32, 64);
     const float invl = 1.f / l;
+    if (SAVE && h == 0) { float *rw = (float *)(svb + SL.oRow); rw[qi] = mxrow; rw[NP + qi] = invl; }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -596,6 +614,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                     const float4 yc = *(const float4 *)&ych[(size_t)qi * DK + d0];      // w * y_chain (own earlier store)
                     store4<IOT>(yp + d0, fmaf(acc[4 * g4], invl, yc.x), fmaf(acc[4 * g4 + 1], invl, yc.y),
                                 fmaf(acc[4 * g4 + 2], invl, yc.z), fmaf(acc[4 * g4 + 3], invl, yc.w));
+                    if (SAVE) *(float4 *)&((float *)(svb + SL.oYb))[(size_t)qi * DK + d0] =
+                        make_float4(acc[4 * g4] * invl, acc[4 * g4 + 1] * invl, acc[4 * g4 + 2] * invl, acc[4 * g4 + 3] * invl);
                 }
             }
         }

@@ -286,6 +286,16 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
         }
     };
 
+    // same for a tile kept as packed fp16 (the backward's Smix / L slabs)
+    auto export_slab_tile_h = [&](u2 *slab, int t16, const f32x4 &x) {
+        for (int wc = w; wc < NT16; wc += NW) {
+            u2 pk;
+            pk[0] = wc == w ? pack_h2(x[0], x[1]) : 0u;
+            pk[1] = wc == w ? pack_h2(x[2], x[3]) : 0u;
+            const int L = 16 * (wc & 1) + n + 32 * (g & 1);
+            slab[((((size_t)(wc >> 1) * KS32 * 2) + t16) * 64 + L) * 2 + (g >> 1)] = pk;
+        }
+    };
     // chain product (transposed, row-block local):  X <- A_{o[V-1]}^T .. A_{o[1]}^T A_{o[0]}^T[:, I]
     float cstr[8];                        // softmax constants c_v of this lane's query (computed by the <- chain, reused by ->)
 #pragma unroll
@@ -556,6 +566,10 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
                 for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) L[h2][i] = mx[h2][i] + __logf(se[h2][i]);   // lse_v S_v - S_0
+                if (SAVE) {
+                    export_slab_tile_h((u2 *)(svb + SL.oL), 2 * s, L[0] * 1.4426950408889634f);
+                    export_slab_tile_h((u2 *)(svb + SL.oL), 2 * s + 1, L[1] * 1.4426950408889634f);
+                }
             }
             // Smix = S0 + (G_and - nb G_not) O + G_or L + G_chain Cr
 #pragma unroll
@@ -575,6 +589,7 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
                 }
                 cw[2 * h2] = pack_h2(sm[0], sm[1]);
                 cw[2 * h2 + 1] = pack_h2(sm[2], sm[3]);
+                if (SAVE) export_slab_tile_h((u2 *)(svb + SL.oSm), t, sm);
             }
             vsel_set(crp, s, cw);
         }
@@ -598,6 +613,11 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float invl = 1.f / l;
+    if (SAVE) {
+        float *rw = (float *)(svb + SL.oRow);
+        if (g == 0) { rw[qi] = mxrow; rw[NP + qi] = invl; }
+        for (int c = tid + 16 * NW; c < NP; c += NTHR) { rw[c] = 0.f; rw[NP + c] = 1.f; }      // queries no wave owns
+    }
 #pragma unroll
     for (int dt = 0; dt < DT16; ++dt) {
         f32x4 acc = zero4;
@@ -610,6 +630,7 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
             const int d0 = 16 * dt + 4 * g;
             const float4 yc = *(const float4 *)&ych[(size_t)qi * DK + d0];      // w * y_chain (own earlier store)
             store4<IOT>(yp + d0, fmaf(acc[0], invl, yc.x), fmaf(acc[1], invl, yc.y), fmaf(acc[2], invl, yc.z), fmaf(acc[3], invl, yc.w));
+            if (SAVE) *(float4 *)&((float *)(svb + SL.oYb))[(size_t)qi * DK + d0] = make_float4(acc[0] * invl, acc[1] * invl, acc[2] * invl, acc[3] * invl);
         }
     }
     FSTAMP();

@@ -134,8 +134,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
     float *dwp = (float *)(ws + W.oDW);
     auto slot = [&](int s) -> u32x4 * {
-        if (SAVED && (s == S_CF || s == S_CB))       // read-only in this mode
-            return (u32x4 *)(svb + (s == S_CF ? SL.oCF : SL.oCB) + (size_t)w * Cfg::SLOT) + lane;
+        if (SAVED && (s == S_CF || s == S_CB || s == S_SM || s == S_L))       // read-only in this mode (the forward's copies)
+            return (u32x4 *)(svb + (s == S_CF ? SL.oCF : s == S_CB ? SL.oCB : s == S_SM ? SL.oSm : SL.oL) + (size_t)w * Cfg::SLOT) + lane;
         return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane;
     };
     // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
@@ -628,7 +628,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     //   running max m, l = sum e, dn = sum e * dP  ->  P = e / l, delta = dn / l.   Smix is parked (fp16) per tile.
     float om = -1e30f, ol = 0.f, odn = 0.f;
 #pragma nounroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < (SAVED ? 0 : NT); ++t) {      // SAVED: the forward exported Smix, L and the row statistics -- no recompute pass
         f32x16 S0, O, L;
         {
             bf16x8 qe[KS];
@@ -695,7 +695,22 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
     }
     float mxrow, invl, delta;
-    {
+    if (SAVED) {
+        // row statistics from the forward; delta_i = sum_j P_ij dP_ij = dy_i . (P v0)_i with the forward's fp32 y_base = P v0
+        const float *rw = (const float *)(svb + SL.oRow), *yb = (const float *)(svb + SL.oYb);
+        mxrow = rw[qi]; invl = rw[NP + qi];
+        float d = 0.f;
+        if (qok) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float4 c0 = *(const float4 *)&yb[(size_t)qi * DK + 16 * s + 8 * h], c1 = *(const float4 *)&yb[(size_t)qi * DK + 16 * s + 8 * h + 4];
+                const float yc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(bf2f((unsigned short)dyf[s][e]), yc[e], d);
+            }
+        }
+        delta = d + __shfl_xor(d, 32, 64);
+    } else {
         const float m2 = __shfl_xor(om, 32, 64), l2 = __shfl_xor(ol, 32, 64), d2 = __shfl_xor(odn, 32, 64);
         mxrow = fmaxf(om, m2);
         const float f1 = __expf(om - mxrow), f2 = __expf(m2 - mxrow);

@@ -112,9 +112,9 @@ __device__ __forceinline__ void key_mean_partials(float *part, const unsigned sh
 // ---- layout of the fused path's `saved` buffer, one record per (b,h).  Inference forward writes only `ych`
 // (w * y_chain, fp32); the training forward additionally exports what the backward would otherwise recompute:
 // the prefix products T_m / U_m as AT images, the final products C-> / C<- as packed per-wave slabs, the per-view
-// softmax constants and the four log-mean vectors.
+// softmax constants, the four log-mean vectors, and the mix phase's Smix / L slabs with the final softmax row statistics.
 struct FusedSavedLayout {
-    size_t oYch, oT, oU, oCF, oCB, oCst, oMeans, stride;
+    size_t oYch, oT, oU, oCF, oCB, oCst, oMeans, oSm, oL, oRow, oYb, stride;
 };
 template <int NT, int DK>
 __host__ __device__ inline FusedSavedLayout fused_saved_layout(int N, int V, bool full) {
@@ -130,6 +130,12 @@ __host__ __device__ inline FusedSavedLayout fused_saved_layout(int N, int V, boo
         L.oCB = o; o += a256(NT * WSLOT);
         L.oCst = o; o += a256((size_t)V * NP * 4);
         L.oMeans = o; o += a256((size_t)4 * NP * 4);
+        // mixed logits Smix and L = lse_v S_v - S_0 (x log2 e) as packed fp16 per-wave slabs, final-softmax row max / 1 / row sum:
+        // with these the backward has no mix-recompute pass
+        L.oSm = o; o += a256(NT * WSLOT);
+        L.oL = o; o += a256(NT * WSLOT);
+        L.oRow = o; o += a256((size_t)2 * NP * 4);
+        L.oYb = o; o += a256((size_t)N * DK * 4);      // y_base = P v0 (fp32): delta_i = sum_j P_ij dP_ij = dy_i . y_base_i
     }
     L.stride = o;
     return L;
