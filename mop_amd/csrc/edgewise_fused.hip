@@ -27,6 +27,14 @@
 #endif
 namespace mopk {
 
+// workgroup barrier for LDS hand-offs: waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// make every barrier wait for the training exports' global stores (nothing in this kernel reads global data another wave wrote)
+#ifndef MOPK_WHATIF_NOBAR
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 template <int NT, int DK, typename IOT, bool SAVE>
 __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs a) {
     using Cfg = FusedCfg<NT, DK>;
@@ -101,16 +109,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             const float t = half_sum32(bf2f((unsigned short)qf[s][j]));
             if (r == 0) colpart[w * DK + 16 * s + 8 * h + j] = t;
         }
-    __syncthreads();                                    // Ksm staged, qbar partials written
+    LDS_BARRIER();                                    // Ksm staged, qbar partials written
     key_mean_partials<NT, DK>(rS, Ksm, N, tid);         // rS is free until the chains are done
-    __syncthreads();
+    LDS_BARRIER();
     if (tid < DK) {
         float sk = 0.f, sq = 0.f;
         for (int p = 0; p < NT * 64 / DK; ++p) sk += rS[p * DK + tid];
         for (int ww = 0; ww < NT; ++ww) sq += colpart[ww * DK + tid];
         kbar[tid] = sk * invN; qbar[tid] = sq * invN;
     }
-    __syncthreads();
+    LDS_BARRIER();
     }
 
     const FusedSavedLayout SL = fused_saved_layout<NT, DK>(N, V, SAVE);
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 make_qe2(qe, v);
                 const float c = view_const(qe, v);
                 FSTAMP2(forward && m == 1);
-                __syncthreads();              // previous step's readers of AT are done
+                LDS_BARRIER();              // previous step's readers of AT are done
                 FSTAMP2(forward && m == 1);
 #pragma unroll 2
                 for (int t = 0; t < NT; ++t) {
@@ -301,7 +309,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                     store_AT_tile(t, lo, hi);
                 }
                 FSTAMP2(forward && m == 1);
-                __syncthreads();
+                LDS_BARRIER();
                 FSTAMP2(forward && m == 1);
             }
             if (m < V - 1) {
@@ -332,7 +340,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         rs += __shfl_xor(rs, 32, 64);
         if (h == 0) rCl[qi] = rs * invN;
     }
-    __syncthreads();
+    LDS_BARRIER();
     if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
     FSTAMP();
     REFRESH();
@@ -362,7 +370,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         }
         rs += __shfl_xor(rs, 32, 64);
         if (h == 0) rCr[qi] = rs * invN;
-        __syncthreads();                      // AT free: build V0^T, VL^T (k-permuted key columns); colpart complete
+        LDS_BARRIER();                      // AT free: build V0^T, VL^T (k-permuted key columns); colpart complete
         {
             const IOT *v0p = (const IOT *)a.v0.ptr + b * a.v0.sb + hh * a.v0.sh;
             const IOT *vLp = (const IOT *)a.vL.ptr + b * a.vL.sb + hh * a.vL.sh;
@@ -386,7 +394,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 float *gc = (float *)(svb + SL.oCst), *gm = (float *)(svb + SL.oMeans);
                 for (int c = tid; c < V * NP; c += NT * 64) gc[c] = cst[c];
                 if (tid < NP) { gm[tid] = rCr[tid]; gm[NP + tid] = rCl[tid]; gm[3 * NP + tid] = cCl[tid]; }
-                __syncthreads();          // cst fully copied before rS/cS overwrite it
+                LDS_BARRIER();          // cst fully copied before rS/cS overwrite it
             }
             // row / col means of S_v are linear in q, k:  rS_v[i] = Qe_v[i,:].kbar ; cS_v[j] = k[j,:].(sqk_v*qbar)
             // (written over the softmax constants `cst`, which the chains no longer need)
@@ -409,7 +417,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 col_means_mfma<NT, DK>(cS, Ksm, sqk, qbar, V, w, r, h);
             }
         }
-        __syncthreads();                      // VT*, cCr, rS, cS complete
+        LDS_BARRIER();                      // VT*, cCr, rS, cS complete
         const float wv = wsig[0];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {     // y_chain^T = VL^T C->^T       :556-560 (as C-> vL); parked in `saved`
@@ -440,7 +448,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         const float *Wg = side ? a.Wc : a.Wr, *bg = side ? a.bc : a.br;
         Wsm[(side * 16 + o) * 19 + (cc < C ? cc : 18)] = cc < C ? Wg[o * C + cc] : bg[o];
     }
-    __syncthreads();
+    LDS_BARRIER();
     for (int p = tid; p < 4 * NP; p += NT * 64) {          // b[g,k,j] -> bT[g][j][slots] = [b_hi | b_hi | b_lo | 0], one (j, g) per thread-iteration
         const int j = p % NP, g = p / NP;
         unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
@@ -474,7 +482,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             af4[g][4 + k] = h == 0 ? (short)lo : (short)0;  // h=0: slots 4-7 a_lo ; h=1: slots 12-15 0
         }
     }
-    __syncthreads();                      // bT complete
+    LDS_BARRIER();                      // bT complete
     FSTAMP();
     REFRESH();
     // ---------------- score-space mix, tile by tile                    :537-547
