@@ -7,8 +7,13 @@ from mop_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 layer = bench.build_layer(torch.bfloat16)
 x = torch.randn(B, 197, 384, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+infer = len(sys.argv) > 2 and sys.argv[2] == "infer"     # inference forward (nothing exported) instead of the training forward
 for _ in range(2):
-    y = layer(x)
+    if infer:
+        with torch.no_grad():
+            y = layer(x)
+    else:
+        y = layer(x)
 torch.cuda.synchronize()
 st = struct.unpack("32Q", ops.LAST_PATH["_fwd_ws"][:256].cpu().numpy().tobytes())
 names = ["P0 stage + means", "chain <-", "chain -> (+exports, V^T, y_chain)", "gate vectors", "mix", "softmax + P V0"]
