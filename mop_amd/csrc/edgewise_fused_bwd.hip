@@ -85,6 +85,11 @@ __device__ __forceinline__ f32x16 unpack_tile_h(u32x4 lo, u32x4 hi) {
     for (int p = 0; p < 4; ++p) { x[2 * p] = h2_lo(lo[p]); x[2 * p + 1] = h2_hi(lo[p]); x[8 + 2 * p] = h2_lo(hi[p]); x[8 + 2 * p + 1] = h2_hi(hi[p]); }
     return x;
 }
+// cond ? x : 0 as a bit mask.  Written as a ternary, hipcc sinks the loads and arithmetic of x under the condition and emits
+// one exec-masked branch (with a full s_waitcnt) per element of a tile; the mask form stays straight-line code.
+__device__ __forceinline__ float keep_if(bool cond, float x) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, x) & (cond ? 0xffffffffu : 0u));
+}
 __device__ __forceinline__ f32x16 zero16() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
 
 template <int NT, int DK, typename IOT, bool SAVED>
@@ -976,7 +981,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * t + tile_row(g, h);
-                    d[g] = (j < N && qok) ? (drl + dmean[(2 * V + 3) * NP + j]) * __builtin_amdgcn_rcpf(cb[g] + EPSC) : 0.f;
+                    d[g] = keep_if(j < N && qok, (drl + dmean[(2 * V + 3) * NP + j]) * __builtin_amdgcn_rcpf(cb[g] + EPSC));
                 }
                 pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
@@ -1011,7 +1016,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * t + tile_row(g, h);
-                    d[g] = (j < N && qok) ? (c3[g] + drr + dmean[(2 * V + 1) * NP + j]) * __builtin_amdgcn_rcpf(cf[g] + EPSC) + wv * dyv[g] : 0.f;
+                    d[g] = keep_if(j < N && qok, (c3[g] + drr + dmean[(2 * V + 1) * NP + j]) * __builtin_amdgcn_rcpf(cf[g] + EPSC) + wv * dyv[g]);
                 }
                 pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
@@ -1103,6 +1108,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     bf16x8 kf[DT][2];
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) { kf[dt][0] = nk[dt][0]; kf[dt][1] = nk[dt][1]; }
+                    // this tile's dA fragments first: when the register allocator keeps the slab in scratch this is a reload, and
+                    // vmcnt is one in-order counter -- requested after the prefetch below, waiting for it would also wait for the prefetch
+                    bf16x8 dl_, dh_;
+                    pk_get(dAp, t, dl_, dh_);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (t + 1 < NT) {
                         nd0 = pd[(2 * t + 2) * 64]; nd1 = pd[(2 * t + 3) * 64];
 #pragma unroll
@@ -1113,14 +1123,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     }
                     const f32x16 A = a_tile(qe, t, cv);
                     const f32x16 dir = unpack_tile_bf(as_b8(d0), as_b8(d1));
-                    bf16x8 dl_, dh_;
-                    pk_get(dAp, t, dl_, dh_);
                     const f32x16 dA = unpack_tile_bf(dl_, dh_);
                     f32x16 dS;
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * t + tile_row(g, h);
-                        dS[g] = j < N ? A[g] * (dA[g] - dot) + dir[g] + drs + dmean[(V + v) * NP + j] : 0.f;
+                        dS[g] = keep_if(j < N, A[g] * (dA[g] - dot) + dir[g] + drs + dmean[(V + v) * NP + j]);
                     }
                     bf16x8 lo, hi;
                     pack_tile_bf(lo, hi, dS);
