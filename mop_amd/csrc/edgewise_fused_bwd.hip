@@ -425,20 +425,31 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     };
     // out[dt] = sum_i Am[32w + r][i] * Bm[d][i]   (rows of this wave's tile of an LDS AT image, B rows d from global)
     auto gemm_rows_glob = [&](f32x16 (&out)[DT], const unsigned short *Am, const unsigned short *Bm) {
+        // the B fragments come from global memory (L2): they are requested GLD k-steps ahead through a register ring, so a step's
+        // MFMAs never wait for a load issued in the same step (one exposed L2 round trip per step otherwise: 28 per call)
+        constexpr int NK = 2 * NT, GLD = 4;
+        const unsigned short *ap = Am + (32 * w + r) * LDA + 8 * h, *bp = Bm + r * LDA + 8 * h;
+        bf16x8 ring[GLD][DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) out[dt] = zero16();
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int k = 0; k < GLD && k < NK; ++k)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 af = *(const bf16x8 *)&(Am + (32 * w + r) * LDA + 8 * h)[32 * t + 16 * s];
+            for (int dt = 0; dt < DT; ++dt) ring[k][dt] = *(const bf16x8 *)&bp[(32 * dt) * LDA + 16 * k];
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 bfr = *(const bf16x8 *)&(Bm + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
-                    out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, out[dt], 0, 0, 0);
-                }
+        for (int k = 0; k < NK; ++k) {
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 af = *(const bf16x8 *)&ap[16 * k];
+            bf16x8 cur[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) cur[dt] = ring[k % GLD][dt];
+            if (k + GLD < NK) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) ring[k % GLD][dt] = *(const bf16x8 *)&bp[(32 * dt) * LDA + 16 * (k + GLD)];
             }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, cur[dt], out[dt], 0, 0, 0);
+        }
     };
     // AT image of a packed slab with a rolled tile loop (uniform switch picks the registers)
     auto store_i_packed = [&](unsigned short *dst, const bf16x8 (&Xp)[NT][2]) {
@@ -1113,12 +1124,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     bf16x8 dl_, dh_;
                     pk_get(dAp, t, dl_, dh_);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (t + 1 < NT) {
-                        nd0 = pd[(2 * t + 2) * 64]; nd1 = pd[(2 * t + 3) * 64];
+                    {   // unconditional (the last iteration re-requests its own tile): a conditional prefetch makes the number of
+                        // outstanding loads unknown at the join and every later s_waitcnt in the iteration becomes vmcnt(0)
+                        const int tn = t + 1 < NT ? t + 1 : t;
+                        nd0 = pd[(2 * tn) * 64]; nd1 = pd[(2 * tn + 1) * 64];
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
-                            nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * (t + 1)];
-                            nk[dt][1] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * (t + 1) + 16];
+                            nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * tn];
+                            nk[dt][1] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * tn + 16];
                         }
                     }
                     const f32x16 A = a_tile(qe, t, cv);
