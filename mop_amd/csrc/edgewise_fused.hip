@@ -91,24 +91,18 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
         if (tid == 0) wsig[0] = 1.f / (1.f + __expf(-*a.chain_logit));
     }
     {
-    bf16x8 qf[KS];
+    // qbar partials: thread (p, d) sums q[j][d] (bf16-rounded like the fragments) over the tokens j = p, p + NT, ... straight from
+    // global memory (independent 2-byte loads); colpart doubles as [NT][DK] scratch here.  (32 five-step lane reductions of the
+    // fragments serialise on their shuffles.)
     {
-        const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (qok) v = load8_bf16<IOT>(qp + 16 * s + 8 * h);
-            qf[s] = v;
+        const int d = tid % DK, p = tid / DK;
+        if (p < NT) {
+            const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + d;
+            float sacc = 0.f;
+            for (int j = p; j < N; j += NT) sacc += bf2f(f2bf(ld_as_f32<IOT>(qp + (int64_t)j * a.q.sn)));
+            colpart[p * DK + d] = sacc;
         }
     }
-    // per-wave partial of qbar (sum over this wave's queries); colpart doubles as [NT][DK] scratch here
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t = half_sum32(bf2f((unsigned short)qf[s][j]));
-            if (r == 0) colpart[w * DK + 16 * s + 8 * h + j] = t;
-        }
     LDS_BARRIER();                                    // Ksm staged, qbar partials written
     key_mean_partials<NT, DK>(rS, Ksm, N, tid);         // rS is free until the chains are done
     LDS_BARRIER();

@@ -220,15 +220,28 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             ((u32x4 *)QT)[c] = ((const u32x4 *)(R + DP * LDA))[c];
             ((u32x4 *)DYT)[c] = ((const u32x4 *)(R + 2 * DP * LDA))[c];
         }
+        // qbar partials from the q^T image (row d = all tokens, padded ones are zero): thread (p, d) sums 32 tokens of row d with
+        // four 16-byte LDS reads.  (32 five-step lane reductions of the q fragments cost ~80 k cycles here: every shuffle waited
+        // on its own scratch-reloaded address.)
+        {
+            const int d = tl % DK, pp = tl / DK;            // NT partials per d (32 tokens each)
+            if (pp < NT) {
+                const unsigned short *qr = R + (DP + d) * LDA + 32 * pp;
+                float sacc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bf16x8 v8 = *(const bf16x8 *)&qr[8 * c];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sacc += bf2f((unsigned short)v8[e]);
+                }
+                colpart[pp * DK + d] = sacc;
+            }
+        }
     }
-    {   // per-wave partial of qbar
+    {
         bf16x8 qf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(qrow + 16 * s + 8 * h); qf[s] = v; }
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float t = half_sum32(bf2f((unsigned short)qf[s][j])); if (r == 0) colpart[w * DK + 16 * s + 8 * h + j] = t; }
         __syncthreads();                                // Ksm staged, qbar partials written
         key_mean_partials<NT, DK>(rS, Ksm, N, tid);     // rS is overwritten with the row means right below
         __syncthreads();
