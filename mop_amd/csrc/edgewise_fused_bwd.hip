@@ -374,11 +374,30 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
         return acc;
     };
+    // two output tiles at once: two independent accumulator chains, so a wave issues an MFMA every 32 cycles instead of waiting
+    // out the 64-cycle dependent-accumulate latency (and its own LDS read) between consecutive MFMAs of one chain
+    auto gemm_tile2 = [&](f32x16 &acc0, f32x16 &acc1, const unsigned short *Am, int to0, const bf16x8 (&Xp)[NT][2]) {
+        const unsigned short *ap = Am + r * LDA + 8 * h + (32 * to0) * LDA;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 af0 = *(const bf16x8 *)&ap[32 * t + 16 * s];
+                const bf16x8 af1 = *(const bf16x8 *)&ap[32 * LDA + 32 * t + 16 * s];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af0, Xp[t][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1, Xp[t][s], acc1, 0, 0, 0);
+            }
+    };
     // Xn = Am . Xp for all output tiles, result re-packed (chain state never exists as an fp32 slab)
     auto gemm_packed = [&](bf16x8 (&Xp)[NT][2], const unsigned short *Am) {
         bf16x8 Xn[NT][2];
 #pragma unroll
-        for (int to = 0; to < NT; ++to) { const f32x16 acc = gemm_tile(zero16(), Am, to, Xp); pack_tile_bf(Xn[to][0], Xn[to][1], acc); }
+        for (int to = 0; to + 1 < NT; to += 2) {
+            f32x16 a0 = zero16(), a1 = zero16();
+            gemm_tile2(a0, a1, Am, to, Xp);
+            pack_tile_bf(Xn[to][0], Xn[to][1], a0); pack_tile_bf(Xn[to + 1][0], Xn[to + 1][1], a1);
+        }
+        if (NT & 1) { const f32x16 acc = gemm_tile(zero16(), Am, NT - 1, Xp); pack_tile_bf(Xn[NT - 1][0], Xn[NT - 1][1], acc); }
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
     };
@@ -1059,10 +1078,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 store_i_packed(R, Dp);
                 lds_barrier();
 #pragma unroll
-                for (int to = 0; to < NT; ++to) {
+                for (int to = 0; to + 1 < NT; to += 2) {
                     __builtin_amdgcn_sched_barrier(0);
-                    const f32x16 acc = gemm_tile(zero16(), R, to, Bf);
-                    pack_tile_bf(dAp[to][0], dAp[to][1], acc);
+                    f32x16 a0 = zero16(), a1 = zero16();
+                    gemm_tile2(a0, a1, R, to, Bf);
+                    pack_tile_bf(dAp[to][0], dAp[to][1], a0); pack_tile_bf(dAp[to + 1][0], dAp[to + 1][1], a1);
+                }
+                if (NT & 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x16 acc = gemm_tile(zero16(), R, NT - 1, Bf);
+                    pack_tile_bf(dAp[NT - 1][0], dAp[NT - 1][1], acc);
                 }
             } else {
 #pragma unroll
@@ -1079,10 +1104,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     store_i_packed(R, Dl);
                     lds_barrier();
 #pragma unroll
-                    for (int to = 0; to < NT; ++to) {
+                    for (int to = 0; to + 1 < NT; to += 2) {
                         __builtin_amdgcn_sched_barrier(0);
-                        const f32x16 acc = gemm_tile(unpack_tile_bf(dAp[to][0], dAp[to][1]), R, to, Bf);
-                        pack_tile_bf(dAp[to][0], dAp[to][1], acc);
+                        f32x16 a0 = unpack_tile_bf(dAp[to][0], dAp[to][1]), a1 = unpack_tile_bf(dAp[to + 1][0], dAp[to + 1][1]);
+                        gemm_tile2(a0, a1, R, to, Bf);
+                        pack_tile_bf(dAp[to][0], dAp[to][1], a0); pack_tile_bf(dAp[to + 1][0], dAp[to + 1][1], a1);
+                    }
+                    if (NT & 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f32x16 acc = gemm_tile(unpack_tile_bf(dAp[NT - 1][0], dAp[NT - 1][1]), R, NT - 1, Bf);
+                        pack_tile_bf(dAp[NT - 1][0], dAp[NT - 1][1], acc);
                     }
                 } else {
 #pragma unroll
