@@ -504,6 +504,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(p[(2 * t) * 64]); Xp[t][1] = as_b8(p[(2 * t + 1) * 64]); }
     };
+    // "all fragments of this slab are needed here": without it hipcc sinks each load of a slot_ld next to the tile that consumes
+    // it (to shorten live ranges), i.e. one exposed memory round trip per tile instead of one per slab
+    auto pin_slab = [&](bf16x8 (&Xp)[NT][2]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(Xp[t][0]), "+v"(Xp[t][1]));
+    };
     // log(C + eps) of one tile: row-sum, per-wave column partials (butterfly: 16 shuffles per tile)
     auto log_tile = [&](f32x16 &X, int t, float &rs) {
         float c[16];
@@ -957,6 +963,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         {
             bf16x8 Xp[NT][2];
             slot_ld(S_CF, Xp);
+            pin_slab(Xp);
             store_i_packed(R, Xp);
         }
         __syncthreads();
@@ -1017,6 +1024,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         {
             bf16x8 Xp[NT][2];
             slot_ld(S_CB, Xp);
+            pin_slab(Xp);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f32x16 cb = unpack_tile_bf(Xp[t][0], Xp[t][1]);
@@ -1050,6 +1058,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             bf16x8 Cp[NT][2], C3[NT][2];
             slot_ld(S_CF, Cp);
             slot_ld(S_C3, C3);
+            pin_slab(Cp); pin_slab(C3);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f32x16 cf = unpack_tile_bf(Cp[t][0], Cp[t][1]);
