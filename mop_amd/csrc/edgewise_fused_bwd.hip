@@ -1210,23 +1210,28 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             REFRESH();
             // ---- dQe_v^T = K^T dS^T ; dq += sqk_v * dQe_v ; dsqk_v = sum_i q * dQe_v
             {
+                // q values of this lane's (query, d) pairs: requested unconditionally and all at once per d-tile (a row that exists is
+                // read for padded queries / d >= dk, the product is masked) -- guarded loads became one branch + full wait per quad
+                const IOT *qsafe = qok ? qrow : (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     float c[16];
+                    float qv[4][4];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int d0 = 32 * dt + 8 * g4 + 4 * h, d0c = d0 < DK ? d0 : 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qv[g4][e] = ld_as_f32(qsafe + d0c + e);
+                    }
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int d0 = 32 * dt + 8 * g4 + 4 * h;
-                        float qv[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (qok && d0 < DK) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) qv[e] = ld_as_f32(qrow + d0 + e);
-                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int g = 4 * g4 + e;
                             const float sc = d0 < DK ? sqk[v * DK + d0 + e] : 0.f;
                             dq_acc[dt][g] = fmaf(sc, dq[dt][g], dq_acc[dt][g]);
-                            c[g] = qok ? qv[e] * dq[dt][g] : 0.f;
+                            c[g] = keep_if(qok && d0 < DK, qv[g4][e] * dq[dt][g]);
                         }
                     }
                     // reduce over the 32 queries of this half (butterfly), lane r even holds register r>>1
