@@ -302,11 +302,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     };
     auto g_tile = [&](const unsigned short *Arows, const bf16x8 (&fr)[KS], int t) -> f32x16 {   // (Arows[j,:] . frag) tile, A from global [NP][DK]
         f32x16 acc = zero16();
+        bf16x8 af[KS];                    // all A fragments requested first (one round trip), then the MFMAs
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bf16x8 af = *(const bf16x8 *)&(Arows + r * DK + 8 * h)[(32 * t) * DK + 16 * s];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, fr[s], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < KS; ++s) af[s] = *(const bf16x8 *)&(Arows + r * DK + 8 * h)[(32 * t) * DK + 16 * s];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(af[s]));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], fr[s], acc, 0, 0, 0);
         return acc;
     };
     constexpr float NEG = -1e30f;                     // finite "-inf" (keeps the online softmax NaN-free)
@@ -893,8 +895,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
     for (int g = 0; g < 8; ++g) dav[tile_row(g, h) * NP + qi] = daacc[g] + daacc[8 + g];
     for (int c = tid; c < 16 * NP; c += NTH) {
+        float pv[NT];                     // the NT partials are requested together (the compiler chained load -> wait -> add otherwise)
+#pragma unroll
+        for (int ww = 0; ww < NT; ++ww) pv[ww] = dbp[(size_t)ww * 16 * NP + c];
+#pragma unroll
+        for (int ww = 0; ww < NT; ++ww) asm volatile("" : "+v"(pv[ww]));
         float s = 0.f;
-        for (int ww = 0; ww < NT; ++ww) s += dbp[(size_t)ww * 16 * NP + c];
+#pragma unroll
+        for (int ww = 0; ww < NT; ++ww) s += pv[ww];
         dbv[c] = s;
     }
     __syncthreads();
