@@ -13,10 +13,12 @@ import os, re, subprocess, sys, tempfile
 
 src = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ""
-defs = [a for a in sys.argv[2:] if a.startswith("-")] or ["-DMOPK_INST_NT=7", "-DMOPK_INST_DK=64"]
+fused = "edgewise_fused" in os.path.basename(src)          # those are built per (NT, DK) instantiation and with relaxed fp
+defs = [a for a in sys.argv[2:] if a.startswith("-")] or (["-DMOPK_INST_NT=7", "-DMOPK_INST_DK=64"] if fused and "16" not in os.path.basename(src) else [])
 out = os.path.join(tempfile.gettempdir(), "isa_waits.s")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffast-math", "-fno-finite-math-only", "-S",
-       "--cuda-device-only", "-o", out, src] + defs
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src] + defs
+if fused:
+    cmd += ["-ffast-math", "-fno-finite-math-only"]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l) and pat in l]
