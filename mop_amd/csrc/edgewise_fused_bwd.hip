@@ -791,9 +791,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma nounroll
     for (int t = 0; t < NT; ++t) {
         f32x16 dS;                                   // dSmix tile
+        // this tile's q / dy fragments are (re)read from L2 in one batch: kept resident across the loop they are spilled and
+        // every use (6 + 1 per tile) starts with its own exposed scratch reload
+        bf16x8 qraw_t[KS], dyf_t[KS];
+        make_frag(qraw_t, qrow, nullptr);
+        make_frag(dyf_t, dyrow, nullptr);
         {
             const f32x16 P = p_tile(t);
-            const f32x16 dP = g_tile(V0s, dyf, t);
+            const f32x16 dP = g_tile(V0s, dyf_t, t);
 #pragma unroll
             for (int g = 0; g < 16; ++g) dS[g] = (32 * t + tile_row(g, h) < N) ? P[g] * (dP[g] - delta) : 0.f;
         }
@@ -812,7 +817,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 lse = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]) * 0.6931471805599453f;   // L = lse - S0 (parked * log2 e)
             }
             for (int v = 0; v < V; ++v) {
-                scale_frag(qe, qraw, sqk + v * DK);
+                scale_frag(qe, qraw_t, sqk + v * DK);
                 const f32x16 Sv = s_tile(qe, t);
                 if (v == 0) lse += Sv; else O += Sv;
                 f32x16 dir;
@@ -831,7 +836,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         f32x16 L, Cr;
         {
             bf16x8 qe[KS];
-            scale_frag(qe, qraw, sqk);
+            scale_frag(qe, qraw_t, sqk);
             const f32x16 S0 = s_tile(qe, t);
             L = lse - S0;
             const u32x4 *pc = slot(S_CF);
@@ -1064,6 +1069,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         {
             const float drr = dmean[(2 * V) * NP + qi];
             bf16x8 Cp[NT][2], C3[NT][2];
+            bf16x8 dyf2[KS];
+            make_frag(dyf2, dyrow, nullptr);
             slot_ld(S_CF, Cp);
             slot_ld(S_C3, C3);
             pin_slab(Cp); pin_slab(C3);
@@ -1071,7 +1078,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             for (int t = 0; t < NT; ++t) {
                 const f32x16 cf = unpack_tile_bf(Cp[t][0], Cp[t][1]);
                 const f32x16 c3 = unpack_tile_bf(C3[t][0], C3[t][1]);
-                const f32x16 dyv = g_tile(VLs, dyf, t);          // (dy vL^T)^T tile
+                const f32x16 dyv = g_tile(VLs, dyf2, t);         // (dy vL^T)^T tile
                 f32x16 d;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
