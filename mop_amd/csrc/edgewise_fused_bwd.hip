@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct BwdWs {
     unsigned char *base;     // workspace base
     size_t stride;           // bytes per workgroup
-    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oDW, oStamp;
+    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oDW, oAcc, oStamp;
 };
 enum { S_CF = 0, S_CB, S_C3, S_L, S_DP, S_SM, S_DIR };   // S_DIR .. S_DIR+V-1 (direct score gradients per view), then S_DL(V) .. +V-1
 __host__ __device__ constexpr int S_DL(int V) { return S_DIR + V; }
@@ -47,6 +47,7 @@ struct BwdCfg {
         w.oStats = o; o += a256((size_t)V * NP * 2 * 4);
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
         w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
+        w.oAcc = o; o += a256((size_t)NT * 2 * DT * 4 * 64 * 16);      // dq / dk accumulators over the views (fp32, [wave][kind][dt][4][lane] x 16 B)
         w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds)
         w.stride = a256(o);
         return w;
@@ -1061,9 +1062,26 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ================= P10: -> chain backward with per-view totals =================
     {
-        f32x16 dq_acc[DT], dk_acc[DT];                 // dq^T [d, my query] and dk [key of tile w, d] summed over views
+        // dq^T [d, my query] and dk [key of tile w, d] summed over views live in the workspace, updated with one batched
+        // read-modify-write per (kind, d-tile) and view: as 64 resident registers they were spilled element by element, each
+        // update a load -> full wait -> fma -> store of its own
+        auto acc_ptr = [&](int kind, int dt) -> f32x4 * {
+            return (f32x4 *)(ws + W.oAcc) + (size_t)((w * 2 + kind) * DT + dt) * 4 * 64 + lane;
+        };
+        // (whole-vector loads / stores only: element-wise writes of a 16-float vector under a branch are miscompiled by hipcc)
+        auto acc_add = [&](int kind, int dt, const f32x16 &x, bool first) {
+            f32x4 *p = acc_ptr(kind, dt);
+            f32x4 acc[4];
+            if (first) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) { dq_acc[dt] = zero16(); dk_acc[dt] = zero16(); }
+                for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = p[i * 64];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i * 64] = acc[i] + f32x4{x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
+        };
         // dC->^T slab, packed tile by tile
         bf16x8 Dp[NT][2];
         {
@@ -1232,6 +1250,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 for (int dt = 0; dt < DT; ++dt) {
                     float c[16];
                     float qv[4][4];
+                    f32x16 dqs;
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int d0 = 32 * dt + 8 * g4 + 4 * h, d0c = d0 < DK ? d0 : 0;
@@ -1245,10 +1264,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         for (int e = 0; e < 4; ++e) {
                             const int g = 4 * g4 + e;
                             const float sc = d0 < DK ? sqk[v * DK + d0 + e] : 0.f;
-                            dq_acc[dt][g] = fmaf(sc, dq[dt][g], dq_acc[dt][g]);
+                            dqs[g] = sc * dq[dt][g];
                             c[g] = keep_if(qok && d0 < DK, qv[g4][e] * dq[dt][g]);
                         }
                     }
+                    acc_add(0, dt, dqs, v == V - 1);
                     // reduce over the 32 queries of this half (butterfly), lane r even holds register r>>1
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
@@ -1281,8 +1301,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 for (int dt = 0; dt < DT; ++dt) {
                     const int d = 32 * dt + r;
                     const float sc = d < DK ? sqk[v * DK + d] : 0.f;
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) dk_acc[dt][g] = fmaf(sc, dk[dt][g], dk_acc[dt][g]);
+                    acc_add(1, dt, dk[dt] * sc, v == V - 1);
                 }
             }
             if (v == V - 1) STAMP();
@@ -1298,13 +1317,18 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         REFRESH();
         {
             IOT *dqp = (IOT *)a.dq.ptr + b * a.dq.sb + hh * a.dq.sh + (int64_t)qi * a.dq.sn;
+            f32x4 dq_acc[DT][4], dk_acc[DT][4];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { dq_acc[dt][i] = acc_ptr(0, dt)[i * 64]; dk_acc[dt][i] = acc_ptr(1, dt)[i * 64]; }
             if (qok) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int d0 = 32 * dt + 8 * g4 + 4 * h;
-                        if (d0 < DK) store4<IOT>(dqp + d0, dq_acc[dt][4 * g4], dq_acc[dt][4 * g4 + 1], dq_acc[dt][4 * g4 + 2], dq_acc[dt][4 * g4 + 3]);
+                        if (d0 < DK) store4<IOT>(dqp + d0, dq_acc[dt][g4][0], dq_acc[dt][g4][1], dq_acc[dt][g4][2], dq_acc[dt][g4][3]);
                     }
             }
             IOT *dkp = (IOT *)a.dk_.ptr + b * a.dk_.sb + hh * a.dk_.sh;
@@ -1315,7 +1339,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * w + tile_row(g, h);
-                        if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, dk_acc[dt][g]);
+                        if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, dk_acc[dt][g >> 2][g & 3]);
                     }
                 }
             }
