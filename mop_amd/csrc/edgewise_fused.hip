@@ -145,11 +145,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     auto make_qe2 = [&](bf16x8 (&qe)[KS], int v) { make_qe_t(qe, sqk2, v); };    // scores * log2(e) (softmax slabs: exp2, no multiply)
     auto s_tile = [&](const bf16x8 (&qe)[KS], int t) -> f32x16 {
         f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 af[KS];                    // all K fragments of the tile requested first: one LDS round trip instead of one per MFMA
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bf16x8 af = *(const bf16x8 *)&(Ksm + r * LDK + 8 * h)[(32 * t) * LDK + 16 * s];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, qe[s], acc, 0, 0, 0);
-        }
+        for (int s = 0; s < KS; ++s) af[s] = *(const bf16x8 *)&(Ksm + r * LDK + 8 * h)[(32 * t) * LDK + 16 * s];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(af[s]));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], qe[s], acc, 0, 0, 0);
         return acc;
     };
     // ---- tile-streamed primitives: no N x 32 fp32 slab is ever held in registers; chain state lives as packed
