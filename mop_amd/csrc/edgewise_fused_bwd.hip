@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         __builtin_amdgcn_sched_barrier(0);
         u32x4 *p = slot(s);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { p[(2 * t) * 64] = as_u4(Xp[t][0]); p[(2 * t + 1) * 64] = as_u4(Xp[t][1]); }
+        for (int t = 0; t < NT; ++t) { __builtin_nontemporal_store(as_u4(Xp[t][0]), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(Xp[t][1]), &p[(2 * t + 1) * 64]); }
     };
     auto slot_ld = [&](int s, bf16x8 (&Xp)[NT][2]) {
         __builtin_amdgcn_sched_barrier(0);
@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
                 bf16x8 bl, bh;
                 pack_tile_bf(bl, bh, dir);
-                u32x4 *p = slot(S_DIR + v); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
+                u32x4 *p = slot(S_DIR + v); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
             }
         }
         // pass 2: gate gradients.  terms: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) c3[g] = dS[g] * G[g];
                 pack_tile_bf(bl, bh, c3);
-                u32x4 *p = slot(S_C3); p[(2 * t) * 64] = as_u4(bl); p[(2 * t + 1) * 64] = as_u4(bh);
+                u32x4 *p = slot(S_C3); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
             }
             // da[rho, i] += sum_j bmat_g[rho][j] dZ^T[j, i]      (rows of gate g4 only)
             bf16x8 zl, zh;
