@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) Bf[t][s] = as_b8(p[(2 * t + s) * 64]);
+            for (int s = 0; s < 2; ++s) Bf[t][s] = as_b8(__builtin_nontemporal_load(&p[(2 * t + s) * 64]));
     };
     // Pk[to] (+)= Am rows . Bf   with the running sum kept as packed bf16 tiles
     auto gemm_acc_packed = [&](bf16x8 (&Pk)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         __builtin_amdgcn_sched_barrier(0);
         const u32x4 *p = slot(s);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(p[(2 * t) * 64]); Xp[t][1] = as_b8(p[(2 * t + 1) * 64]); }
+        for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(__builtin_nontemporal_load(&p[(2 * t) * 64])); Xp[t][1] = as_b8(__builtin_nontemporal_load(&p[(2 * t + 1) * 64])); }
     };
     // "all fragments of this slab are needed here": without it hipcc sinks each load of a slot_ld next to the tile that consumes
     // it (to shorten live ranges), i.e. one exposed memory round trip per tile instead of one per slab
