@@ -815,7 +815,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             bf16x8 qe[KS];
             {
                 const u32x4 *p = slot(S_L);
-                lse = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]) * 0.6931471805599453f;   // L = lse - S0 (parked * log2 e)
+                lse = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), __builtin_nontemporal_load(&p[(2 * t + 1) * 64])) * 0.6931471805599453f;   // L = lse - S0 (parked * log2 e)
             }
             for (int v = 0; v < V; ++v) {
                 scale_frag(qe, qraw_t, sqk + v * DK);
@@ -1194,7 +1194,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 // while tile t is computed (a rolled loop exposes one full L2/HBM round trip per iteration otherwise)
                 const u32x4 *pd = slot(S_DIR + v);
                 const unsigned short *ktb = KT + r * LDA + 8 * h;
-                u32x4 nd0 = pd[0], nd1 = pd[64];
+                u32x4 nd0 = __builtin_nontemporal_load(&pd[0]), nd1 = __builtin_nontemporal_load(&pd[64]);
                 bf16x8 nk[DT][2];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) { nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA]; nk[dt][1] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 16]; }
@@ -1213,7 +1213,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     {   // unconditional (the last iteration re-requests its own tile): a conditional prefetch makes the number of
                         // outstanding loads unknown at the join and every later s_waitcnt in the iteration becomes vmcnt(0)
                         const int tn = t + 1 < NT ? t + 1 : t;
-                        nd0 = pd[(2 * tn) * 64]; nd1 = pd[(2 * tn + 1) * 64];
+                        nd0 = __builtin_nontemporal_load(&pd[(2 * tn) * 64]); nd1 = __builtin_nontemporal_load(&pd[(2 * tn + 1) * 64]);
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * tn];
