@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
                     pk[0] = real ? pack_bf16(tr[0], tr[1]) : 0u;
                     pk[1] = real ? pack_bf16(tr[2], tr[3]) : 0u;
                     const int L = n + 16 * h2 + 32 * (g & 1);
-                    out[(((size_t)s * 2 * KS32 + wc) * 64 + L) * 2 + (g >> 1)] = pk;
+                    __builtin_nontemporal_store(pk, &out[(((size_t)s * 2 * KS32 + wc) * 64 + L) * 2 + (g >> 1)]);
                 }
         }
     };
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
             pk[0] = wc == w ? pack_bf16(x[0], x[1]) : 0u;
             pk[1] = wc == w ? pack_bf16(x[2], x[3]) : 0u;
             const int L = 16 * (wc & 1) + n + 32 * (g & 1);
-            slab[((((size_t)(wc >> 1) * KS32 * 2) + t16) * 64 + L) * 2 + (g >> 1)] = pk;
+            __builtin_nontemporal_store(pk, &slab[((((size_t)(wc >> 1) * KS32 * 2) + t16) * 64 + L) * 2 + (g >> 1)]);
         }
     };
 
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(KS32 * 128) ew16_fwd_kernel(MopkEdgewiseArgs a
             pk[0] = wc == w ? pack_h2(x[0], x[1]) : 0u;
             pk[1] = wc == w ? pack_h2(x[2], x[3]) : 0u;
             const int L = 16 * (wc & 1) + n + 32 * (g & 1);
-            slab[((((size_t)(wc >> 1) * KS32 * 2) + t16) * 64 + L) * 2 + (g >> 1)] = pk;
+            __builtin_nontemporal_store(pk, &slab[((((size_t)(wc >> 1) * KS32 * 2) + t16) * 64 + L) * 2 + (g >> 1)]);
         }
     };
     // chain product (transposed, row-block local):  X <- A_{o[V-1]}^T .. A_{o[1]}^T A_{o[0]}^T[:, I]
