@@ -697,7 +697,7 @@ size_t ew_fused_saved_bytes(const MopkEdgewiseArgs *a) {
 int ew16_fwd_supported(const MopkEdgewiseArgs *a);
 int ew16_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
 // MOPK_EW16=1 (read per call) routes the shapes it covers to the 16-query-wave forward instead: an experiment kept for A/B
-// timing -- at the bench shape it is 12 % slower than the 32-query kernel, so it is off by default
+// timing -- at the bench shape it is 15-27 % slower than the 32-query kernel, so it is off by default
 static bool ew16_enabled() { const char *e = getenv("MOPK_EW16"); return e && e[0] == '1'; }
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     if (!ew_fused_fwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
