@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     }
     auto p_tile = [&](int t) -> f32x16 {      // P tile from the parked Smix
         const u32x4 *p = slot(S_SM);
-        f32x16 x = unpack_tile_h(p[(2 * t) * 64], p[(2 * t + 1) * 64]);
+        f32x16 x = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), __builtin_nontemporal_load(&p[(2 * t + 1) * 64]));
 #pragma unroll
         for (int g = 0; g < 16; ++g) x[g] = __expf(x[g] - mxrow) * invl;
         return x;
