@@ -367,3 +367,53 @@ def test_vit_edgewise_trains_on_the_fused_path():
     losses = [float(step(x, y)) for _ in range(30)]
     assert ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_FUSED
     assert all(l == l for l in losses) and losses[-1] < 0.6 * losses[0], losses[::5]
+
+
+def test_token_linear_gradients_match_nn_linear_on_gpu():
+    """TokenLinear's batched weight-gradient GEMM (bf16 slices, fp32 sum) against nn.Linear's single GEMM at the bench shape."""
+    import torch.nn as nn
+    from mop_amd.nn.linear import TokenLinear
+    torch.manual_seed(0)
+    ref = nn.Linear(384, 1152, bias=True).cuda().to(torch.bfloat16)
+    lin = TokenLinear(384, 1152, bias=True).cuda().to(torch.bfloat16)
+    lin.load_state_dict(ref.state_dict())
+    x = torch.randn(64, 197, 384, device="cuda", dtype=torch.bfloat16)
+    w = torch.randn(64, 197, 1152, device="cuda", dtype=torch.bfloat16)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = ref(xa), lin(xb)
+    assert torch.equal(ya, yb)
+    (ya * w).sum().backward(); (yb * w).sum().backward()
+    gw64 = (w.double().flatten(0, 1).t() @ x.double().flatten(0, 1))          # fp64 reference of dW
+    err_ref = (ref.weight.grad.double() - gw64).abs().max() / gw64.abs().max()
+    err_new = (lin.weight.grad.double() - gw64).abs().max() / gw64.abs().max()
+    assert float(err_new) <= max(2.0 * float(err_ref), 5e-3)                  # at least as accurate as the single GEMM
+    assert torch.allclose(xa.grad.float(), xb.grad.float(), rtol=0, atol=0)  # dX is the same hipBLASLt GEMM
+    assert float((lin.bias.grad.double() - w.double().sum((0, 1))).abs().max() / w.double().sum((0, 1)).abs().max()) <= 1e-2
+
+
+def test_reduce_parts_matches_a_host_side_sum():
+    """mopk_edgewise_reduce_parts (one launch, fixed order) against torch sums of the same partial buffers; bitwise repeatable."""
+    import ctypes as C
+    from mop_amd import _lib as L
+    lib = L.lib()
+    B, V, H, dk = 37, 5, 6, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    parts = [torch.randn(B, V, H, dk, device="cuda", generator=g), torch.randn(B, H, dk, device="cuda", generator=g),
+             torch.randn(B, H, dk, device="cuda", generator=g), torch.randn(B, H, device="cuda", generator=g)]
+    a = L.EdgewiseArgs()
+    a.B, a.H, a.V, a.dk = B, H, V, dk
+    a.dsqk_part, a.dvs0_part, a.dvsL_part, a.dlogit_part = (p.data_ptr() for p in parts)
+    outs = []
+    for _ in range(2):
+        o = [torch.empty(V, H, dk, device="cuda"), torch.empty(H, dk, device="cuda"), torch.empty(H, dk, device="cuda"), torch.empty(1, device="cuda")]
+        rc = lib.mopk_edgewise_reduce_parts(C.byref(a), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr(),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append(o)
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    exp = [parts[0].double().sum(0), parts[1].double().sum(0), parts[2].double().sum(0), parts[3].double().sum().reshape(1)]
+    for x, e in zip(outs[0], exp):
+        assert float((x.double() - e).abs().max()) <= 1e-4 * max(1.0, float(e.abs().max()))
+    assert lib.mopk_edgewise_reduce_parts(None, 0, 0, 0, 0, None) == -2 or lib.mopk_edgewise_reduce_parts(None, 0, 0, 0, 0, None) < 0
