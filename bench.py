@@ -130,6 +130,10 @@ def main():
         if world > 1:  # one flat gradient bucket, one RCCL all-reduce over xGMI
             bucket.allreduce_(average=True)
 
+    # one untimed initialisation pass (code-object loading, hipBLASLt kernel selection by TunableOp, allocator growth), so that the
+    # W warm-up steps -- and with --warmup 0 the timed steps -- run the steady-state path
+    step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     ops.enable_timing(True)
