@@ -994,13 +994,22 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             float s0 = 0.f, sL = 0.f;
             if (d < DK) {
                 const float f0 = vs0[d], fL = vsL[d] * wv;
+                // the v0 / vL values of this lane's 16 keys are requested together from rows that exist (padded keys read row 0 and
+                // are masked): guarded, each pair of loads sat in its own exec-masked branch with a full wait (32 per lane)
+                float x0[16], xL[16];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int j = 32 * w + tile_row(g, h), jc = j < N ? j : 0;
+                    x0[g] = ld_as_f32(v0p + (int64_t)jc * a.v0.sn + d);
+                    xL[g] = ld_as_f32(vLp + (int64_t)jc * a.vL.sn + d);
+                }
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * w + tile_row(g, h);
+                    const float e0 = g0[dt][g], eL = gL[dt][g] * wv;
+                    s0 += keep_if(j < N, e0 * x0[g]);
+                    sL += keep_if(j < N, eL * xL[g]);
                     if (j < N) {
-                        const float e0 = g0[dt][g], eL = gL[dt][g] * wv;
-                        s0 = fmaf(e0, ld_as_f32(v0p + (int64_t)j * a.v0.sn + d), s0);
-                        sL = fmaf(eL, ld_as_f32(vLp + (int64_t)j * a.vL.sn + d), sL);
                         if (same) st_from_f32(d0p + (int64_t)j * a.dv0.sn + d, e0 * f0 + gL[dt][g] * fL);
                         else { st_from_f32(d0p + (int64_t)j * a.dv0.sn + d, e0 * f0); st_from_f32(dLp + (int64_t)j * a.dvL.sn + d, gL[dt][g] * fL); }
                     }
