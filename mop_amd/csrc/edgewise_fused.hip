@@ -449,28 +449,54 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     for (int p = tid; p < 4 * NP; p += NT * 64) {          // b[g,k,j] -> bT[g][j][slots] = [b_hi | b_hi | b_lo | 0], one (j, g) per thread-iteration
         const int j = p % NP, g = p / NP;
         unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
-        if (j < N)
-            for (int k = 0; k < R; ++k) {
-                const float *Wo = Wsm + (16 + g * R + k) * 19;
-                float s = Wo[18];
-                for (int c = 0; c < V; ++c) s = fmaf(Wo[c], cS[c * NP + j], fmaf(Wo[V + c], rS[c * NP + j], s));
-                s = fmaf(Wo[2 * V], cCr[j], fmaf(Wo[2 * V + 1], cCl[j], s));
-                hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
+        if (j < N) {
+            // the (up to) four rank channels of this gate side by side: four independent fma chains, every feature read once
+            const float *Wg4 = Wsm + (16 + g * R) * 19;
+            float sk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sk[k] = Wg4[(k < R ? k : 0) * 19 + 18];
+            for (int c = 0; c < V; ++c) {
+                const float fc = cS[c * NP + j], fr = rS[c * NP + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < R ? k : 0) * 19; sk[k] = fmaf(Wo[c], fc, fmaf(Wo[V + c], fr, sk[k])); }
             }
+            {
+                const float f0 = cCr[j], f1 = cCl[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < R ? k : 0) * 19; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < R) { hi[k] = f2bf(sk[k]); lo[k] = f2bf(sk[k] - bf2f(hi[k])); }
+        }
         unsigned short *row = bT + (g * NP + j) * BTS;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0; }
     }
     bf16x8 af4[4];                        // a[g,k,i] as B fragments: slots [a_hi | a_lo | a_hi | 0]
+    float av16[4][4];                      // a[g,k] for this lane's query: 16 independent fma chains over the feature channels
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av16[g][k] = Wsm[(g * R + (k < R ? k : 0)) * 19 + 18];
+    for (int c = 0; c < V; ++c) {
+        const float fr = rS[c * NP + qi], fc = cS[c * NP + qi];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * R + (k < R ? k : 0)) * 19; av16[g][k] = fmaf(Wo[c], fr, fmaf(Wo[V + c], fc, av16[g][k])); }
+    }
+    {
+        const float f0 = rCr[qi], f1 = rCl[qi];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * R + (k < R ? k : 0)) * 19; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
+    }
+#pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float av[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < R; ++k) {
-            const float *Wo = Wsm + (g * R + k) * 19;
-            float s = Wo[18];
-            for (int c = 0; c < V; ++c) s = fmaf(Wo[c], rS[c * NP + qi], fmaf(Wo[V + c], cS[c * NP + qi], s));
-            s = fmaf(Wo[2 * V], rCr[qi], fmaf(Wo[2 * V + 1], rCl[qi], s));
-            av[k] = s;
-        }
+        float av[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av[k] = k < R ? av16[g][k] : 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float a2 = av[k] * 1.4426950408889634f;               // gate logits come out pre-scaled by log2(e): sigmoid = 1/(1+2^-z')
