@@ -629,14 +629,25 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         const int j = p % NP, g = p / NP;
         const int col = (j & ~15) + kperm16(j & 15);
         unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
-        if (j < N)
-            for (int k = 0; k < RK; ++k) {
-                const float *Wo = Wsm + (16 + g * RK + k) * 19;
-                float s = Wo[18];
-                for (int c = 0; c < V; ++c) s = fmaf(Wo[c], cS[c * NP + j], fmaf(Wo[V + c], rS[c * NP + j], s));
-                s = fmaf(Wo[2 * V], cCr[j], fmaf(Wo[2 * V + 1], cCl[j], s));
-                hi[k] = f2bf(s); lo[k] = f2bf(s - bf2f(hi[k]));
+        if (j < N) {
+            // the (up to) four rank channels of this gate side by side: four independent fma chains, every feature read once
+            const float *Wg4 = Wsm + (16 + g * RK) * 19;
+            float sk[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sk[k] = Wg4[(k < RK ? k : 0) * 19 + 18];
+            for (int c = 0; c < V; ++c) {
+                const float fc = cS[c * NP + j], fr = rS[c * NP + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < RK ? k : 0) * 19; sk[k] = fmaf(Wo[c], fc, fmaf(Wo[V + c], fr, sk[k])); }
             }
+            {
+                const float f0 = cCr[j], f1 = cCl[j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < RK ? k : 0) * 19; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < RK) { hi[k] = f2bf(sk[k]); lo[k] = f2bf(sk[k] - bf2f(hi[k])); }
+        }
         unsigned short *row = bT + (g * NP + j) * BTS;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -646,15 +657,30 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
     }
     bf16x8 af4[4];
+    float av16[4][4];                      // a[g,k] for this lane's query: 16 independent fma chains over the feature channels
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av16[g][k] = Wsm[(g * RK + (k < RK ? k : 0)) * 19 + 18];
+    for (int c = 0; c < V; ++c) {
+        const float fr = rS[c * NP + qi], fc = cS[c * NP + qi];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * RK + (k < RK ? k : 0)) * 19; av16[g][k] = fmaf(Wo[c], fr, fmaf(Wo[V + c], fc, av16[g][k])); }
+    }
+    {
+        const float f0 = rCr[qi], f1 = rCl[qi];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * RK + (k < RK ? k : 0)) * 19; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
+    }
+#pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float av[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < RK; ++k) {
-            const float *Wo = Wsm + (g * RK + k) * 19;
-            float s = Wo[18];
-            for (int c = 0; c < V; ++c) s = fmaf(Wo[c], rS[c * NP + qi], fmaf(Wo[V + c], cS[c * NP + qi], s));
-            s = fmaf(Wo[2 * V], rCr[qi], fmaf(Wo[2 * V + 1], rCl[qi], s));
-            av[k] = s;
-        }
+        float av[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av[k] = k < RK ? av16[g][k] : 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const unsigned short hi = f2bf(av[k]), lo = f2bf(av[k] - bf2f(hi));
