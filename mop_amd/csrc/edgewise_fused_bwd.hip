@@ -1,12 +1,19 @@
-// EdgewiseMSA low-rank core -- fused gfx950 BACKWARD kernel (bf16 MFMA, fp32 accumulate).
+// EdgewiseMSA low-rank core -- fused gfx950 BACKWARD kernels (bf16 MFMA, fp32 accumulate).
 //
 // One workgroup per (batch, head), NT = ceil(N/32) waves, wave w owns queries I = [32w, 32w+32).
-// The forward is recomputed on-chip (same X-layout chains as edgewise_fused.hip); the only N x N data
-// that touches memory are bf16 images this workgroup writes and re-reads itself (L2 / Infinity Cache):
-//   * T_m^T, U_m^T prefix products in "AT format" (rows = keys, k-permuted query columns): the B operand
-//     of dA_m = T_{m-1}^T D_m, whose contraction runs over queries (= lanes in the X layout);
-//   * per-wave register slabs parked as packed bf16/fp16 (C->, C<-, the <- chain's D slabs, the direct
-//     score gradients c0..c3, lse-S0).
+// The backward is THREE launches of one kernel template (template parameter PH), each with its own register allocation
+// (as one kernel the phases' live ranges overlapped: 83-213 spilled VGPRs, dq / dk accumulators and the chain state
+// parked in memory -- 16.6 GB of traffic per launch at B = 256, 61 x the algorithmic I/O):
+//   PH_A  mix backward: dSmix, gate-head gradients, mean gradients, dv; exports the direct score gradients per view,
+//         G_chain * dSmix and the mean-gradient vectors into the per-(b,h) hand-off region;
+//   PH_B  the two D-chains (D_{m-1}^T = A_m D_m^T, row-block local), one work item per (b,h, chain); every D_m is
+//         exported as a packed per-wave slab;
+//   PH_C  per view: dA_v = T_{v-1}^T D_v + U^T D' (two GEMMs), softmax backward + direct + mean terms -> dS_v,
+//         dQe_v, dK_v; dq / dk accumulate over the views IN REGISTERS.
+// It needs the chain / mix state the training forward exports (`saved`, edgewise_fused.hip); when the caller asked for the
+// small `saved` (save_for_backward = 0) the host re-runs the forward in export mode into the workspace first.
+// The only N x N data that touches memory are packed bf16 / fp16 per-wave register slabs (one coalesced 1 KiB store per
+// fragment) and the forward's prefix products T_m, U_m in the backward's load order.
 // Gradient flow (oracle/edgewise.py::core_bwd): dy -> dP, dSmix -> gate grads (da via MFMA on the
 // register tile, db via a 32x32 LDS transpose + MFMA) -> mean grads -> dC->, dC<- -> the two D-chains
 // (D_{m-1}^T = A_m D_m^T, row-block local) -> per view: dA_v (two GEMMs) -> softmax backward + direct +
@@ -17,13 +24,21 @@ namespace mopk {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+enum { PH_A = 0, PH_B = 1, PH_C = 2 };       // the three launches of the backward (see the header comment)
+
 struct BwdWs {
-    unsigned char *base;     // workspace base
+    unsigned char *base;     // per-workgroup scratch (persistent workgroups: indexed by blockIdx)
     size_t stride;           // bytes per workgroup
-    size_t oT, oU, oKT, oQT, oDYT, oV0s, oVLs, oSlots, oStats, oDbp, oDW, oAcc, oStamp;
+    size_t oKT, oQT, oDYT, oV0s, oVLs, oDbp, oDW, oStamp;
+    unsigned char *xbase;    // per-(b,h) hand-off region between the three launches
+    size_t xstride;
+    size_t xSlots, xDmean;
 };
-enum { S_CF = 0, S_CB, S_C3, S_L, S_DP, S_SM, S_DIR };   // S_DIR .. S_DIR+V-1 (direct score gradients per view), then S_DL(V) .. +V-1
-__host__ __device__ constexpr int S_DL(int V) { return S_DIR + V; }
+// slab ids.  S_CF .. S_L live in the forward's `saved` record; X_* in the hand-off region
+enum { S_CF = 0, S_CB, S_SM, S_L, X_C3, X_DIR };   // X_DIR .. X_DIR+V-1 (direct score gradients per view), X_DR(V)+v: D_v of the -> chain, X_DL(V)+m: D'_m of the <- chain
+__host__ __device__ constexpr int X_DR(int V) { return X_DIR + V; }
+__host__ __device__ constexpr int X_DL(int V) { return X_DIR + 2 * V; }
+__host__ __device__ constexpr int X_COUNT(int V) { return 1 + 3 * V; }      // slabs in the hand-off region (ids X_C3 ..)
 
 template <int NT, int DK>
 struct BwdCfg {
@@ -32,25 +47,31 @@ struct BwdCfg {
     static constexpr size_t MAT = (size_t)NP * LDA * 2;
     static constexpr size_t SLOT = (size_t)NT * 8 * 64 * 4;                // one packed slab of one wave
     static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
-    static BwdWs carve(void *base, int V, bool saved) {      // saved: prefix products live in the forward's `saved` buffer
+    // base: nwg per-workgroup scratch regions, then nbh hand-off regions
+    static BwdWs carve(void *base, int V, int nwg, int nbh) {
         BwdWs w{};
         size_t o = 0;
         w.base = (unsigned char *)base;
-        w.oT = o; o += saved ? 0 : a256((size_t)(V - 1) * MAT);
-        w.oU = o; o += saved ? 0 : a256((size_t)(V - 1) * MAT);
         w.oKT = o; o += a256((size_t)DP * LDA * 2);
         w.oQT = o; o += a256((size_t)DP * LDA * 2);
         w.oDYT = o; o += a256((size_t)DP * LDA * 2);
         w.oV0s = o; o += a256((size_t)NP * DK * 2);
         w.oVLs = o; o += a256((size_t)NP * DK * 2);
-        w.oSlots = o; o += a256((size_t)(S_DL(V) + V) * NT * SLOT);
-        w.oStats = o; o += a256((size_t)V * NP * 2 * 4);
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
         w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
-        w.oAcc = o; o += a256((size_t)NT * 2 * DT * 4 * 64 * 16);      // dq / dk accumulators over the views (fp32, [wave][kind][dt][4][lane] x 16 B)
         w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds)
         w.stride = a256(o);
+        w.xbase = w.base + w.stride * (size_t)nwg;
+        size_t x = 0;
+        w.xSlots = x; x += a256((size_t)X_COUNT(V) * NT * SLOT);
+        w.xDmean = x; x += a256((size_t)(2 * V + 4) * NP * 4);
+        w.xstride = a256(x);
+        (void)nbh;
         return w;
+    }
+    static size_t total_bytes(int V, int nwg, int nbh) {
+        const BwdWs w = carve(nullptr, V, nwg, nbh);
+        return w.stride * (size_t)nwg + w.xstride * (size_t)nbh;
     }
     // LDS: R region | Ksm | floats
     static constexpr int GATE_BYTES = 4 * NP * BTS * 2 + 2 * 32 * LDA * 2 + NT * 32 * 40 * 2;   // bT | bmat | amat | tbuf
@@ -93,7 +114,7 @@ __device__ __forceinline__ float keep_if(bool cond, float x) {
 }
 __device__ __forceinline__ f32x16 zero16() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
 
-template <int NT, int DK, typename IOT, bool SAVED>
+template <int NT, int DK, typename IOT, int PH>
 __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W) {
     using Cfg = BwdCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = DK + 8, KS = DK / 16, DT = Cfg::DT, DP = Cfg::DP;
@@ -129,20 +150,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     const int C = 2 * V + 2;
 
     unsigned char *ws = W.base + (size_t)blockIdx.x * W.stride;
-    const FusedSavedLayout SL = fused_saved_layout<NT, DK>(a.N, a.V, SAVED);
-    const unsigned char *svb = (const unsigned char *)a.saved;          // record of the current (b,h) (set per iteration)
-    // SAVED: the forward exported the prefix products, final products, softmax constants and log-means -> no recompute
-    const unsigned short *Tg = (const unsigned short *)(ws + W.oT), *Ug = (const unsigned short *)(ws + W.oU);
+    const FusedSavedLayout SL = fused_saved_layout<NT, DK>(a.N, a.V, true);
+    const unsigned char *svb = (const unsigned char *)a.saved;          // forward's record of the current (b,h) (set per iteration):
+    const unsigned short *Tg = nullptr, *Ug = nullptr;                  //   prefix products, final products, softmax constants, log-means, mix state
+    unsigned char *xf = W.xbase;                                        // hand-off region of the current (b,h)
     unsigned short *KT = (unsigned short *)(ws + W.oKT), *QT = (unsigned short *)(ws + W.oQT), *DYT = (unsigned short *)(ws + W.oDYT);
     unsigned short *V0s = (unsigned short *)(ws + W.oV0s), *VLs = (unsigned short *)(ws + W.oVLs);
-    float *stats = (float *)(ws + W.oStats);                          // [V][NP] softmax constants c_v[i] (log2 of the row sum of 2^S')
-    const float *cstats = stats;                                      // read side (SAVED: the forward's copy)
+    const float *cstats = nullptr;                                    // [V][NP] softmax constants c_v[i] (log2 of the row sum of 2^S'), from the forward
     float *dbp = (float *)(ws + W.oDbp);                              // [NT][16][NP]
     float *dwp = (float *)(ws + W.oDW);
     auto slot = [&](int s) -> u32x4 * {
-        if (SAVED && (s == S_CF || s == S_CB || s == S_SM || s == S_L))       // read-only in this mode (the forward's copies)
+        if (s < X_C3)                                                        // read-only: the forward's copies
             return (u32x4 *)(svb + (s == S_CF ? SL.oCF : s == S_CB ? SL.oCB : s == S_SM ? SL.oSm : SL.oL) + (size_t)w * Cfg::SLOT) + lane;
-        return (u32x4 *)(ws + W.oSlots + ((size_t)s * NT + w) * Cfg::SLOT) + lane;
+        return (u32x4 *)(xf + W.xSlots + ((size_t)(s - X_C3) * NT + w) * Cfg::SLOT) + lane;
     };
     // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
 
@@ -158,22 +178,28 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #else
 #define STAMP2() do { } while (0)
 #endif
-    // persistent workgroup: scratch is indexed by blockIdx (stays hot in L2 / Infinity Cache), (b,h) pairs are strided
-    for (int bh = blockIdx.x; bh < a.B * H; bh += gridDim.x) {
+    // persistent workgroup: scratch is indexed by blockIdx, work items are strided.  PH_B has two items per (b,h): the two chains
+    constexpr int ITEMS = PH == PH_B ? 2 : 1;
+    for (int item = blockIdx.x; item < a.B * H * ITEMS; item += gridDim.x) {
+    const int bh = item / ITEMS, chain_id = item % ITEMS;
     const int b = bh / H, hh = bh % H;
-    const bool first_pass = bh == (int)blockIdx.x;
+    const bool first_pass = item == (int)blockIdx.x;
     svb = (const unsigned char *)a.saved + (size_t)bh * SL.stride;
+    xf = W.xbase + (size_t)bh * W.xstride;
+    float *xdmean = (float *)(xf + W.xDmean);                          // [(2V+4)][NP] mean gradients (PH_A -> PH_B, PH_C)
     const float *ych = (const float *)(svb + SL.oYch);                 // w * y_chain from the fused forward
-    if (SAVED) {
-        Tg = (const unsigned short *)(svb + SL.oT); Ug = (const unsigned short *)(svb + SL.oU);
-        cstats = (const float *)(svb + SL.oCst);
-    }
+    Tg = (const unsigned short *)(svb + SL.oT); Ug = (const unsigned short *)(svb + SL.oU);
+    cstats = (const float *)(svb + SL.oCst);
     STAMP();
     REFRESH();                           // per (b,h): nothing lane-derived may be hoisted out of the persistent loop (it would be spilled)
     const IOT *qrow = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh + (int64_t)qi * a.q.sn;
     const IOT *dyrow = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)qi * a.dy.sn;
 
-    // ================= P0: stage operands =================
+    // ================= P0: stage operands (each launch stages only what it reads) =================
+    //   PH_A: K (LDS), dy^T image, V0 rows (scaled), q^T in LDS for the query mean; row / col means of the scores
+    //   PH_B: K (LDS), VL rows (scaled)          PH_C: K (LDS), k^T and q^T images
+    constexpr bool NEED_KT = PH == PH_C, NEED_QT = PH == PH_C, NEED_QT_LDS = PH != PH_B, NEED_DYT = PH == PH_A;
+    constexpr bool NEED_V0 = PH == PH_A, NEED_VL = PH == PH_B;
     {
         const int tl = 64 * w + lane;      // == tid, but derived from the refreshed lane id
         const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh;
@@ -184,16 +210,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int c = tl; c < V * DK; c += NTH) { const float t = a.sqk[((c / DK) * H + hh) * DK + (c % DK)]; sqk[c] = t; sqk2[c] = t * 1.4426950408889634f; }
         for (int c = tl; c < DK; c += NTH) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
         if (tid == 0) misc[0] = 1.f / (1.f + __expf(-*a.chain_logit));
+        if (PH != PH_A) {                  // mean gradients of this (b,h) from PH_A
+            for (int c = tl; c < (2 * V + 4) * NP; c += NTH) dmean[c] = xdmean[c];
+        }
         constexpr int CH = DK / 8;
         for (int c = tl; c < NP * CH; c += NTH) {
             const int j = c / CH, dc = c % CH;
             bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, qv = kv, dv = kv, x0 = kv, xL = kv;
             if (j < N) {
                 kv = load8_bf16<IOT>(kp + (int64_t)j * a.k.sn + dc * 8);
-                qv = load8_bf16<IOT>(qp + (int64_t)j * a.q.sn + dc * 8);
-                dv = load8_bf16<IOT>(dp + (int64_t)j * a.dy.sn + dc * 8);
-                x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8);
-                xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8);
+                if (NEED_QT_LDS) qv = load8_bf16<IOT>(qp + (int64_t)j * a.q.sn + dc * 8);
+                if (NEED_DYT) dv = load8_bf16<IOT>(dp + (int64_t)j * a.dy.sn + dc * 8);
+                if (NEED_V0) x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8);
+                if (NEED_VL) xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8);
             }
             *(bf16x8 *)&Ksm[j * LDK + dc * 8] = kv;
             const int col = (j & ~15) + kperm16(j & 15);
@@ -204,27 +233,27 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int d = dc * 8 + e;
-                // the three transposed images are assembled in LDS (R is free here) and exported with 16-byte stores
-                R[d * LDA + col] = (unsigned short)kv[e];
-                R[(DP + d) * LDA + col] = (unsigned short)qv[e];
-                R[(2 * DP + d) * LDA + col] = (unsigned short)dv[e];
+                // the transposed images are assembled in LDS (R is free here) and exported with 16-byte stores
+                if (NEED_KT) R[d * LDA + col] = (unsigned short)kv[e];
+                if (NEED_QT_LDS) R[(DP + d) * LDA + col] = (unsigned short)qv[e];
+                if (NEED_DYT) R[(2 * DP + d) * LDA + col] = (unsigned short)dv[e];
                 s0[e] = (short)f2bf(bf2f((unsigned short)x0[e]) * sc0[e]);
                 sL[e] = (short)f2bf(bf2f((unsigned short)xL[e]) * scL[e]);
             }
-            *(bf16x8 *)&V0s[j * DK + dc * 8] = s0;
-            *(bf16x8 *)&VLs[j * DK + dc * 8] = sL;
+            if (NEED_V0) *(bf16x8 *)&V0s[j * DK + dc * 8] = s0;
+            if (NEED_VL) *(bf16x8 *)&VLs[j * DK + dc * 8] = sL;
         }
         if (DK < DP) for (int c = tl; c < (DP - DK) * LDA; c += NTH) { R[DK * LDA + c] = 0; R[(DP + DK) * LDA + c] = 0; R[(2 * DP + DK) * LDA + c] = 0; }
         __syncthreads();
         for (int c = tl; c < DP * LDA / 8; c += NTH) {
-            ((u32x4 *)KT)[c] = ((const u32x4 *)R)[c];
-            ((u32x4 *)QT)[c] = ((const u32x4 *)(R + DP * LDA))[c];
-            ((u32x4 *)DYT)[c] = ((const u32x4 *)(R + 2 * DP * LDA))[c];
+            if (NEED_KT) ((u32x4 *)KT)[c] = ((const u32x4 *)R)[c];
+            if (NEED_QT) ((u32x4 *)QT)[c] = ((const u32x4 *)(R + DP * LDA))[c];
+            if (NEED_DYT) ((u32x4 *)DYT)[c] = ((const u32x4 *)(R + 2 * DP * LDA))[c];
         }
         // qbar partials from the q^T image (row d = all tokens, padded ones are zero): thread (p, d) sums 32 tokens of row d with
         // four 16-byte LDS reads.  (32 five-step lane reductions of the q fragments cost ~80 k cycles here: every shuffle waited
         // on its own scratch-reloaded address.)
-        {
+        if (PH == PH_A) {
             const int d = tl % DK, pp = tl / DK;            // NT partials per d (32 tokens each)
             if (pp < NT) {
                 const unsigned short *qr = R + (DP + d) * LDA + 32 * pp;
@@ -239,7 +268,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
         }
     }
-    {
+    if (PH == PH_A) {
         bf16x8 qf[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(qrow + 16 * s + 8 * h); qf[s] = v; }
@@ -264,6 +293,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
         col_means_mfma<NT, DK>(cS, Ksm, sqk, qbar, V, w, r, h);
     }
+    __syncthreads();                     // P0 global images + LDS complete
     const float wv = misc[0];
 
     // ================= helpers =================
@@ -311,34 +341,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], fr[s], acc, 0, 0, 0);
         return acc;
-    };
-    constexpr float NEG = -1e30f;                     // finite "-inf" (keeps the online softmax NaN-free)
-    // softmax constant of this lane's query for view v (scores pre-scaled by log2 e), online over key tiles:
-    //   c = log2 sum_j 2^(S'[i,j])  ->  A_v[i,j] = 2^(S'[i,j] - c);  parked in `stats`; only tail tiles pay for the mask
-    auto row_const = [&](const bf16x8 (&qe)[KS], int v) -> float {
-        float m = NEG, l = 0.f;
-#pragma nounroll
-        for (int t = 0; t < NT; ++t) {
-            f32x16 S = s_tile(qe, t);
-            if (32 * t + 32 > N) {
-#pragma unroll
-                for (int g = 0; g < 16; ++g) S[g] = (32 * t + tile_row(g, h) >= N) ? NEG : S[g];     // select (no per-lane branch around a vector element write)
-            }
-            float tm = NEG;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) tm = fmaxf(tm, S[g]);
-            const float mn = fmaxf(m, tm);
-            float sm = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) sm += __builtin_amdgcn_exp2f(S[g] - mn);
-            l = fmaf(l, __builtin_amdgcn_exp2f(m - mn), sm);
-            m = mn;
-        }
-        const float m2 = __shfl_xor(m, 32, 64), l2 = __shfl_xor(l, 32, 64);
-        const float mx = fmaxf(m, m2);
-        const float c = mx + __builtin_amdgcn_logf(l * __builtin_amdgcn_exp2f(m - mx) + l2 * __builtin_amdgcn_exp2f(m2 - mx));
-        if (h == 0) stats[v * NP + qi] = c;
-        return c;
     };
     auto a_tile = [&](const bf16x8 (&qe)[KS], int t, float c) -> f32x16 {   // one tile of A_v^T (keys >= N -> 0)
         f32x16 S = s_tile(qe, t);
@@ -513,42 +515,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(Xp[t][0]), "+v"(Xp[t][1]));
     };
-    // log(C + eps) of one tile: row-sum, per-wave column partials (butterfly: 16 shuffles per tile)
-    auto log_tile = [&](f32x16 &X, int t, float &rs) {
-        float c[16];
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const float v = __logf(X[g] + EPSC);
-            X[g] = v;
-            rs += (32 * t + tile_row(g, h) < N) ? v : 0.f;
-            c[g] = qok ? v : 0.f;
-        }
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int n = 8 >> st;
-            const bool up = (r >> (4 - st)) & 1;
-#pragma unroll
-            for (int k = 0; k < n; ++k) {
-                const float keep = up ? c[k + n] : c[k], send = up ? c[k] : c[k + n];
-                c[k] = keep + __shfl_xor(send, 16 >> st, 64);
-            }
-        }
-        c[0] += __shfl_xor(c[0], 1, 64);
-        if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
-    };
-    // copy the AT image staged in R to a global image with coalesced 16-byte accesses (all threads)
-    auto export_R = [&](unsigned short *dst) {                 // AT image in R -> global "row slab" order (see load_rows)
-        u32x4 *out = (u32x4 *)dst;
-        for (int c = tid; c < NT * 2 * NT * 64; c += NTH) {
-            const int L = c & 63, q = (c >> 6) % (2 * NT), ws_ = (c >> 6) / (2 * NT);
-            out[c] = *(const u32x4 *)&R[(32 * ws_ + (L & 31)) * LDA + 16 * q + 8 * (L >> 5)];
-        }
-    };
     // image of A_v (form ii) or A_v^T (form i) streamed tile by tile into dst (LDS)
-    auto a_image = [&](unsigned short *dst, int v, bool form_ii, bool have_stats) {
+    auto a_image = [&](unsigned short *dst, int v, bool form_ii) {
         bf16x8 qe[KS];
         make_frag(qe, qrow, sqk2 + v * DK);
-        const float c = have_stats ? cstats[v * NP + qi] : row_const(qe, v);
+        const float c = cstats[v * NP + qi];
         lds_barrier();                    // previous readers of dst are done
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
@@ -558,61 +529,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
         lds_barrier();
     };
-    // forward chain recompute on packed state; every prefix product T_m (m = 0..V-2) is staged in R (AT format)
-    // and copied to Pg[m]; returns the final product in Xp
-    auto run_chain = [&](bf16x8 (&Xp)[NT][2], bool forward, unsigned short *Pg) {   // !SAVED only
-        {
-            const int v = forward ? 0 : V - 1;
-            bf16x8 qe[KS];
-            make_frag(qe, qrow, sqk2 + v * DK);
-            const float c = forward ? stats[v * NP + qi] : row_const(qe, v);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, c); pack_tile_bf(Xp[t][0], Xp[t][1], A); }
-        }
-        for (int m = 1; m < V; ++m) {
-            lds_barrier();                    // R free (previous GEMM / export readers done)
-            store_i_packed(R, Xp);            // T_{m-1}^T image
-            __syncthreads();
-            export_R(Pg + (size_t)(m - 1) * NP * LDA);
-            a_image(R, forward ? m : V - 1 - m, false, forward);   // the <- chain (run first) computed every view's constant
-            gemm_packed(Xp, R);
-        }
-    };
-    // means of log(C + eps) from the packed product; optional packed fp16 copy of the log
-    auto log_means_packed = [&](const bf16x8 (&Xp)[NT][2], float *rout, unsigned int (*cr)[8]) {
-        float rs = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x16 c = unpack_tile_bf(Xp[t][0], Xp[t][1]);
-            log_tile(c, t, rs);
-            if (cr) {
-#pragma unroll
-                for (int p = 0; p < 8; ++p) cr[t][p] = pack_h2(c[2 * p], c[2 * p + 1]);
-            }
-        }
-        rs += __shfl_xor(rs, 32, 64);
-        if (h == 0) rout[qi] = rs * invN;
-    };
-
     STAMP();
     REFRESH();
-    // ================= P1/P2: forward chains (recompute) =================
-    __syncthreads();                     // P0 global images + LDS complete
-    if (SAVED) {
+    if constexpr (PH == PH_A) {
+    // ================= log-means of the chain products (from the forward) =================
+    {
         const float *gm = (const float *)(svb + SL.oMeans);
         if (tid < NP) { rCr[tid] = gm[tid]; rCl[tid] = gm[NP + tid]; cCr[tid] = gm[2 * NP + tid]; cCl[tid] = gm[3 * NP + tid]; }
-    } else {
-        bf16x8 Xp[NT][2];
-        run_chain(Xp, false, (unsigned short *)Ug);
-        slot_st(S_CB, Xp);
-        log_means_packed(Xp, rCl, nullptr);
-        __syncthreads();
-        if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCl[tid] = c * invN; }
-        run_chain(Xp, true, (unsigned short *)Tg);
-        slot_st(S_CF, Xp);
-        log_means_packed(Xp, rCr, nullptr);
-        __syncthreads();
-        if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; cCr[tid] = c * invN; }
     }
     __syncthreads();
     STAMP();
@@ -694,7 +617,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     __syncthreads();
     STAMP();
     REFRESH();
-    // ================= P4: mix recompute -> Smix (crp), L parked =================
+    // ================= P4: mix state: Smix / L slabs and the final softmax row statistics come from the forward =================
     const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
     auto gate_tile = [&](int t, int g4) -> f32x16 {
         const bf16x8 bfrag = *(const bf16x8 *)&bT[(g4 * NP + 32 * t + r) * BTS + 8 * h];
@@ -703,83 +626,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int g = 0; g < 16; ++g) z[g] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z[g]));
         return z;
     };
-    bf16x8 qraw[KS];                     // raw q fragments, resident through the mix phases (P4-P6)
-    make_frag(qraw, qrow, nullptr);
     bf16x8 dyf[KS];
     make_frag(dyf, dyrow, nullptr);
-    // online softmax over key tiles of the mixed logits, fused with delta_i = sum_j P dP (dP tile = V0 dy^T):
-    //   running max m, l = sum e, dn = sum e * dP  ->  P = e / l, delta = dn / l.   Smix is parked (fp16) per tile.
-    float om = -1e30f, ol = 0.f, odn = 0.f;
-#pragma nounroll
-    for (int t = 0; t < (SAVED ? 0 : NT); ++t) {      // SAVED: the forward exported Smix, L and the row statistics -- no recompute pass
-        f32x16 S0, O, L;
-        {
-            bf16x8 qe[KS];
-            scale_frag(qe, qraw, sqk);
-            S0 = s_tile(qe, t);
-            f32x16 mx = zero16(), se;
-            O = mx;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) se[g] = 1.f;
-            for (int v = 1; v < V; ++v) {
-                scale_frag(qe, qraw, sqk + v * DK);
-                const f32x16 Sv = s_tile(qe, t);
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    O[g] += Sv[g];
-                    const float d = Sv[g] - S0[g];
-                    const float e = __expf(-fabsf(d - mx[g]));
-                    se[g] = d > mx[g] ? fmaf(se[g], e, 1.f) : se[g] + e;
-                    mx[g] = fmaxf(mx[g], d);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) L[g] = mx[g] + __logf(se[g]);
-        }
-        {
-            u32x4 lo, hi;
-            pack_tile_h(lo, hi, L * 1.4426950408889634f);            // parked as L * log2(e): the dS pass works in base 2
-            u32x4 *p = slot(S_L);
-            p[(2 * t) * 64] = lo; p[(2 * t + 1) * 64] = hi;
-        }
-        { const f32x16 G = gate_tile(t, 0);
-#pragma unroll
-          for (int g = 0; g < 16; ++g) S0[g] = fmaf(G[g], O[g], S0[g]); }
-        { const f32x16 G = gate_tile(t, 1);
-#pragma unroll
-          for (int g = 0; g < 16; ++g) S0[g] = fmaf(G[g], L[g], S0[g]); }
-        { const f32x16 G = gate_tile(t, 2);
-#pragma unroll
-          for (int g = 0; g < 16; ++g) S0[g] = fmaf(-nb * G[g], O[g], S0[g]); }
-        {
-            const f32x16 G = gate_tile(t, 3);
-            const u32x4 *pc = slot(S_CF);
-            const f32x16 cf = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
-            float tm = -1e30f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                float sm = fmaf(G[g], __logf(cf[g] + EPSC), S0[g]);
-                if (32 * t + tile_row(g, h) >= N) sm = -1e30f;
-                S0[g] = sm;
-                tm = fmaxf(tm, sm);
-            }
-            u32x4 lo, hi;
-            pack_tile_h(lo, hi, S0);
-            u32x4 *p = slot(S_SM);
-            p[(2 * t) * 64] = lo; p[(2 * t + 1) * 64] = hi;
-            const f32x16 dP = g_tile(V0s, dyf, t);
-            const f32x16 Sq = unpack_tile_h(lo, hi);          // the fp16-rounded logits every later pass sees
-            const float mn = fmaxf(om, tm);
-            float sl = 0.f, sd = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) { const float e = __expf(Sq[g] - mn); sl += e; sd = fmaf(e, dP[g], sd); }
-            const float f = __expf(om - mn);
-            ol = fmaf(ol, f, sl); odn = fmaf(odn, f, sd); om = mn;
-        }
-    }
     float mxrow, invl, delta;
-    if (SAVED) {
-        // row statistics from the forward; delta_i = sum_j P_ij dP_ij = dy_i . (P v0)_i with the forward's fp32 y_base = P v0
+    {
+        // delta_i = sum_j P_ij dP_ij = dy_i . (P v0)_i with the forward's fp32 y_base = P v0
         const float *rw = (const float *)(svb + SL.oRow), *yb = (const float *)(svb + SL.oYb);
         mxrow = rw[qi]; invl = rw[NP + qi];
         float d = 0.f;
@@ -793,13 +644,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
         }
         delta = d + __shfl_xor(d, 32, 64);
-    } else {
-        const float m2 = __shfl_xor(om, 32, 64), l2 = __shfl_xor(ol, 32, 64), d2 = __shfl_xor(odn, 32, 64);
-        mxrow = fmaxf(om, m2);
-        const float f1 = __expf(om - mxrow), f2 = __expf(m2 - mxrow);
-        const float lt = ol * f1 + l2 * f2;
-        invl = 1.f / lt;
-        delta = (odn * f1 + d2 * f2) * invl;
     }
     auto p_tile = [&](int t) -> f32x16 {      // P tile from the parked Smix
         const u32x4 *p = slot(S_SM);
@@ -856,7 +700,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
                 bf16x8 bl, bh;
                 pack_tile_bf(bl, bh, dir);
-                u32x4 *p = slot(S_DIR + v); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
+                u32x4 *p = slot(X_DIR + v); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
             }
         }
         // pass 2: gate gradients.  terms: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
@@ -887,7 +731,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) c3[g] = dS[g] * G[g];
                 pack_tile_bf(bl, bh, c3);
-                u32x4 *p = slot(S_C3); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
+                u32x4 *p = slot(X_C3); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
             }
             // da[rho, i] += sum_j bmat_g[rho][j] dZ^T[j, i]      (rows of gate g4 only)
             bf16x8 zl, zh;
@@ -985,7 +829,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         sr = fmaf(Wsm[o * 19 + (cr >= 0 ? cr : 0)], dav[rho * NP + n], sr);
                         sc = fmaf(Wsm[(16 + o) * 19 + (cc >= 0 ? cc : 0)], dbv[rho * NP + n], sc);
                     }
-            dmean[item] = ((cr >= 0 ? sr : 0.f) + (cc >= 0 ? sc : 0.f)) * invN;
+            const float dm = ((cr >= 0 ? sr : 0.f) + (cc >= 0 ? sc : 0.f)) * invN;
+            xdmean[item] = dm;                // hand-off: PH_B / PH_C stage these vectors in their own LDS
         }
         __syncthreads();
     }
@@ -1069,9 +914,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         if (tid == 0) { float s = 0.f; for (int ww = 0; ww < NT; ++ww) s += misc[4 + ww]; a.dlogit_part[(int64_t)b * H + hh] = s * (1.f - wv); }
     }
     STAMP();
+    }   // PH_A
+    if constexpr (PH == PH_B) {
+    // ================= PH_B: the two D-chains, one work item per chain; every D_m is exported as a packed slab =================
     REFRESH();
-    // ================= P9: <- chain backward: D'_m slabs parked in S_DL+m =================
-    {
+    if (chain_id == 1) {
+        // <- chain: D'_{V-1} = dC<- = (drCl_i + dcCl_j) / (C<- + eps);  D'_{m-1}^T = A_{V-1-m} D'_m^T
         const float drl = dmean[(2 * V + 2) * NP + qi];
         bf16x8 Dp[NT][2];
         {
@@ -1091,37 +939,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
         }
         for (int m = V - 1; m >= 1; --m) {
-            slot_st(S_DL(V) + m, Dp);
-            a_image(R, V - 1 - m, true, true);         // A_av (rows = queries)
+            slot_st(X_DL(V) + m, Dp);
+            a_image(R, V - 1 - m, true);               // A_av (rows = queries)
             gemm_packed(Dp, R);                        // D'_{m-1}^T = A_av D'_m^T
         }
-        slot_st(S_DL(V), Dp);
-    }
-    STAMP();
-    REFRESH();
-    // ================= P10: -> chain backward with per-view totals =================
-    {
-        // dq^T [d, my query] and dk [key of tile w, d] summed over views live in the workspace, updated with one batched
-        // read-modify-write per (kind, d-tile) and view: as 64 resident registers they were spilled element by element, each
-        // update a load -> full wait -> fma -> store of its own
-        auto acc_ptr = [&](int kind, int dt) -> f32x4 * {
-            return (f32x4 *)(ws + W.oAcc) + (size_t)((w * 2 + kind) * DT + dt) * 4 * 64 + lane;
-        };
-        // (whole-vector loads / stores only: element-wise writes of a 16-float vector under a branch are miscompiled by hipcc)
-        auto acc_add = [&](int kind, int dt, const f32x16 &x, bool first) {
-            f32x4 *p = acc_ptr(kind, dt);
-            f32x4 acc[4];
-            if (first) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = p[i * 64];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) p[i * 64] = acc[i] + f32x4{x[4 * i], x[4 * i + 1], x[4 * i + 2], x[4 * i + 3]};
-        };
-        // dC->^T slab, packed tile by tile
+        slot_st(X_DL(V), Dp);
+    } else {
+        // -> chain: D_{V-1} = dC-> = (G_chain dSmix + drCr_i + dcCr_j) / (C-> + eps) + w dy vL^T;  D_{v-1}^T = A_v D_v^T
         bf16x8 Dp[NT][2];
         {
             const float drr = dmean[(2 * V) * NP + qi];
@@ -1129,7 +953,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             bf16x8 dyf2[KS];
             make_frag(dyf2, dyrow, nullptr);
             slot_ld(S_CF, Cp);
-            slot_ld(S_C3, C3);
+            slot_ld(X_C3, C3);
             pin_slab(Cp); pin_slab(C3);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -1145,9 +969,25 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
         }
+        for (int v = V - 1; v >= 1; --v) {
+            slot_st(X_DR(V) + v, Dp);
+            a_image(R, v, true);
+            gemm_packed(Dp, R);                        // D_{v-1}^T = A_v D_v^T
+        }
+        slot_st(X_DR(V), Dp);
+    }
+    }   // PH_B
+    if constexpr (PH == PH_C) {
+    // ================= PH_C: per view dA_v -> dS_v -> dQe_v, dK_v; dq / dk summed over the views in registers =================
+    REFRESH();
+    {
+        f32x16 dqa[DT], dka[DT];           // dq^T [d, my query] and dk [key of tile w, d], summed over the views
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dqa[dt] = zero16(); dka[dt] = zero16(); }
         for (int v = V - 1; v >= 0; --v) {
-            slot_st(S_DP, Dp);                         // park D_v (B operand of the D-chain step below)
             REFRESH();
+            bf16x8 Dp[NT][2];
+            slot_ld(X_DR(V) + v, Dp);                  // D_v of the -> chain (PH_B)
             // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index), kept as packed bf16 tiles; the
             //      softmax-backward row dot  sum_j A_v dA_v  is taken from the fp32 accumulators of the LAST contribution
             bf16x8 dAp[NT][2];
@@ -1177,7 +1017,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             {
                 bf16x8 Dl[NT][2];
                 __builtin_amdgcn_sched_barrier(0);   // keep these loads below GEMM 1 (register pressure)
-                slot_ld(S_DL(V) + mp, Dl);
+                slot_ld(X_DL(V) + mp, Dl);
                 if (mp >= 1) {
                     bf16x8 Bf[NT][2];
                     load_rows(Bf, Ug + (size_t)(mp - 1) * NP * LDA);
@@ -1231,7 +1071,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 const float drs = dmean[v * NP + qi];
                 // software prefetch: the parked direct-gradient tile and the K^T fragments of tile t+1 are requested
                 // while tile t is computed (a rolled loop exposes one full L2/HBM round trip per iteration otherwise)
-                const u32x4 *pd = slot(S_DIR + v);
+                const u32x4 *pd = slot(X_DIR + v);
                 const unsigned short *ktb = KT + r * LDA + 8 * h;
                 u32x4 nd0 = __builtin_nontemporal_load(&pd[0]), nd1 = __builtin_nontemporal_load(&pd[64]);
                 bf16x8 nk[DT][2];
@@ -1307,7 +1147,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                             c[g] = keep_if(qok && d0 < DK, qv[g4][e] * dq[dt][g]);
                         }
                     }
-                    acc_add(0, dt, dqs, v == V - 1);
+                    dqa[dt] += dqs;
                     // reduce over the 32 queries of this half (butterfly), lane r even holds register r>>1
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
@@ -1340,34 +1180,23 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 for (int dt = 0; dt < DT; ++dt) {
                     const int d = 32 * dt + r;
                     const float sc = d < DK ? sqk[v * DK + d] : 0.f;
-                    acc_add(1, dt, dk[dt] * sc, v == V - 1);
+                    dka[dt] += dk[dt] * sc;
                 }
             }
             if (v == V - 1) STAMP();
             REFRESH();
-            // ---- D_{v-1}^T = A_v D_v^T
-            if (v >= 1) {
-                slot_ld(S_DP, Dp);                 // issued early: consumed after the A_v image is staged
-                a_image(R, v, true, true);
-                gemm_packed(Dp, R);
-            }
         }
         // ================= P11: write dq, dk =================
         REFRESH();
         {
             IOT *dqp = (IOT *)a.dq.ptr + b * a.dq.sb + hh * a.dq.sh + (int64_t)qi * a.dq.sn;
-            f32x4 dq_acc[DT][4], dk_acc[DT][4];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { dq_acc[dt][i] = acc_ptr(0, dt)[i * 64]; dk_acc[dt][i] = acc_ptr(1, dt)[i * 64]; }
             if (qok) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int d0 = 32 * dt + 8 * g4 + 4 * h;
-                        if (d0 < DK) store4<IOT>(dqp + d0, dq_acc[dt][g4][0], dq_acc[dt][g4][1], dq_acc[dt][g4][2], dq_acc[dt][g4][3]);
+                        if (d0 < DK) store4<IOT>(dqp + d0, dqa[dt][4 * g4], dqa[dt][4 * g4 + 1], dqa[dt][4 * g4 + 2], dqa[dt][4 * g4 + 3]);
                     }
             }
             IOT *dkp = (IOT *)a.dk_.ptr + b * a.dk_.sb + hh * a.dk_.sh;
@@ -1378,14 +1207,15 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * w + tile_row(g, h);
-                        if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, dk_acc[dt][g >> 2][g & 3]);
+                        if (j < N) st_from_f32(dkp + (int64_t)j * a.dk_.sn + d, dka[dt][g]);
                     }
                 }
             }
         }
     }
+    }   // PH_C
     STAMP();
-    __syncthreads();      // LDS / scratch reuse by the next (b,h)
+    __syncthreads();      // LDS / scratch reuse by the next work item
     }   // persistent loop
     STAMP();
 }
@@ -1394,30 +1224,59 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #define MOPK_CAT_(a, b, c, d) a##b##c##d
 #define MOPK_CAT(a, b, c, d) MOPK_CAT_(a, b, c, d)
 #if MOPK_INST_NT != 0
-static int bwd_grid(const MopkEdgewiseArgs *a) { const int bh = a->B * a->H; return bh < 256 ? bh : 256; }   // one persistent WG per CU
+static int bwd_grid(const MopkEdgewiseArgs *a, int items_per_bh) {       // one persistent workgroup per CU
+    const int n = a->B * a->H * items_per_bh;
+    return n < 256 ? n : 256;
+}
+static size_t a256h(size_t x) { return (x + 255) & ~(size_t)255; }
+// workspace = [per-workgroup scratch x grid | per-(b,h) hand-off x B*H | (save_for_backward == 0 only) full `saved` record + y scratch
+// for the forward re-run in export mode]
+static size_t bwd_core_bytes(const MopkEdgewiseArgs *a) {
+    return a256h(BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::total_bytes(a->V, bwd_grid(a, 2), a->B * a->H));   // scratch for the widest grid (PH_B)
+}
+static size_t bwd_full_saved_bytes(const MopkEdgewiseArgs *a) {
+    return a256h(fused_saved_layout<MOPK_INST_NT, MOPK_INST_DK>(a->N, a->V, true).stride * (size_t)a->B * a->H + 256);
+}
 size_t MOPK_CAT(ew_fused_bwd_ws_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a) {
-    return BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::carve(nullptr, a->V, a->save_for_backward != 0).stride * (size_t)bwd_grid(a) + 256;
+    size_t n = bwd_core_bytes(a) + 256;
+    if (!a->save_for_backward) n += bwd_full_saved_bytes(a) + a256h((size_t)a->B * a->H * a->N * a->dk * 4);
+    return n;
 }
 void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st);
-int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st) {
+int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st);
+int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a_in, hipStream_t st) {
     constexpr int NT = MOPK_INST_NT, DK = MOPK_INST_DK;
     using Cfg = BwdCfg<NT, DK>;
-    const int lds = Cfg::lds_bytes(a->V);
-    if (lds > 160 * 1024 || 2 * a->V + 2 > 18) return MOPK_ERR_UNSUPPORTED;
-    const BwdWs W = Cfg::carve(a->workspace, a->V, a->save_for_backward != 0);
-    const int nwg = bwd_grid(a);
-    const dim3 grid(nwg), block(NT * 64);
-#define MOPK_LAUNCH(IOT_, SAVED_) do {                                                                            \
-        auto kfn = ew_fused_bwd_kernel<NT, DK, IOT_, SAVED_>;                                                     \
+    const int lds = Cfg::lds_bytes(a_in->V);
+    if (lds > 160 * 1024 || 2 * a_in->V + 2 > 18) return MOPK_ERR_UNSUPPORTED;
+    MopkEdgewiseArgs args = *a_in;
+    if (!a_in->save_for_backward) {
+        // small `saved`: rebuild the full record (chain + mix state) by running the forward in export mode into the workspace
+        unsigned char *rb = (unsigned char *)a_in->workspace + bwd_core_bytes(a_in);
+        MopkEdgewiseArgs f = *a_in;
+        f.save_for_backward = 1;
+        f.saved = rb;
+        f.y.ptr = rb + bwd_full_saved_bytes(a_in);
+        f.y.sb = (int64_t)a_in->H * a_in->N * a_in->dk; f.y.sh = (int64_t)a_in->N * a_in->dk; f.y.sn = a_in->dk;
+        const int rc = MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(&f, st);
+        if (rc != MOPK_OK) return rc;
+        args.saved = rb;
+        args.save_for_backward = 1;
+    }
+    const MopkEdgewiseArgs *a = &args;
+    const int nwgA = bwd_grid(a, 1), nwgB = bwd_grid(a, 2);
+    const BwdWs W = Cfg::carve(a->workspace, a->V, nwgB, a->B * a->H);     // nwgB >= nwgA
+    const dim3 block(NT * 64);
+#define MOPK_LAUNCH(IOT_, PH_, GRID_) do {                                                                        \
+        auto kfn = ew_fused_bwd_kernel<NT, DK, IOT_, PH_>;                                                        \
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, W);                                                     \
+        hipLaunchKernelGGL(kfn, dim3(GRID_), block, lds, st, *a, W);                                              \
     } while (0)
-    // save_for_backward must match the forward call that filled `saved`
-    if (a->io_dtype == MOPK_BF16) { if (a->save_for_backward) MOPK_LAUNCH(unsigned short, true); else MOPK_LAUNCH(unsigned short, false); }
-    else { if (a->save_for_backward) MOPK_LAUNCH(float, true); else MOPK_LAUNCH(float, false); }
+    if (a->io_dtype == MOPK_BF16) { MOPK_LAUNCH(unsigned short, PH_A, nwgA); MOPK_LAUNCH(unsigned short, PH_B, nwgB); MOPK_LAUNCH(unsigned short, PH_C, nwgA); }
+    else { MOPK_LAUNCH(float, PH_A, nwgA); MOPK_LAUNCH(float, PH_B, nwgB); MOPK_LAUNCH(float, PH_C, nwgA); }
 #undef MOPK_LAUNCH
     MOPK_CHECK_LAUNCH();
-    ew_fused_dw_reduce(a, W, nwg, st);
+    ew_fused_dw_reduce(a, W, nwgA, st);
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
 }

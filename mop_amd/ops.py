@@ -88,6 +88,7 @@ def _f32_pack(ts):
 
 # ---- optional kernel timing (bench.py): HIP events on the stream the kernels are launched on ----
 LAST_PATH = {}  # entry point -> MopkPath actually requested on the last call (tests assert on it)
+_KEEP_WS = bool(__import__("os").environ.get("MOPK_STAMPS"))  # stamp builds only: keep the last workspace tensors alive for read-back
 _TIMING = None  # dict name -> list[(start_event, stop_event)] when enabled
 
 
@@ -187,7 +188,8 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
         ws = _bytes(256 if path == L.PATH_FUSED else lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
-        LAST_PATH["_fwd_ws"] = ws  # kept for diagnostics (stamp builds read it back)
+        if _KEEP_WS:
+            LAST_PATH["_fwd_ws"] = ws  # diagnostics only (stamp builds read it back): pins the buffer until the next call
         with _timed("edgewise_fwd"):
             rc = lib.mopk_edgewise_lowrank_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_lowrank_fwd")
@@ -232,7 +234,8 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.dlogit_part = dlg_p.data_ptr()
         LAST_PATH["edgewise_bwd"] = path
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
-        LAST_PATH["_bwd_ws"] = ws  # kept for diagnostics (stamp builds read it back)
+        if _KEEP_WS:
+            LAST_PATH["_bwd_ws"] = ws  # diagnostics only (stamp builds read it back): pins the buffer until the next call
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("edgewise_bwd"):
             rc = lib.mopk_edgewise_lowrank_bwd(C.byref(a), _stream())
