@@ -26,6 +26,8 @@ if os.environ.get("MOPK_STAMPS"):  # diagnostic build: s_memtime stamps per phas
     FLAGS.append("-DMOPK_STAMPS")
     if os.environ["MOPK_STAMPS"] == "2":  # plus sub-phase stamps (shifts the phase names of tools/stamps.py)
         FLAGS.append("-DMOPK_STAMPS2")
+    # which launch of the split backward writes the stamps: A / B / C (default C)
+    FLAGS.append("-DMOPK_STAMP_PH=" + {"A": "0", "B": "1", "C": "2"}[os.environ.get("MOPK_STAMP_PH", "C")])
 
 
 def _hipcc() -> str:

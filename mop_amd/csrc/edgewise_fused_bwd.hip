@@ -52,6 +52,7 @@ struct BwdCfg {
         BwdWs w{};
         size_t o = 0;
         w.base = (unsigned char *)base;
+        w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds): first, so tools find them at the workspace base
         w.oKT = o; o += a256((size_t)DP * LDA * 2);
         w.oQT = o; o += a256((size_t)DP * LDA * 2);
         w.oDYT = o; o += a256((size_t)DP * LDA * 2);
@@ -59,7 +60,6 @@ struct BwdCfg {
         w.oVLs = o; o += a256((size_t)NP * DK * 2);
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
         w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
-        w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds)
         w.stride = a256(o);
         w.xbase = w.base + w.stride * (size_t)nwg;
         size_t x = 0;
@@ -169,7 +169,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #ifdef MOPK_STAMPS
     unsigned long long *stamps = (unsigned long long *)(ws + W.oStamp);
     int stamp_i = 0;
-#define STAMP() do { if (blockIdx.x == 0 && tid == 0 && stamp_i < 60) stamps[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
+#ifndef MOPK_STAMP_PH
+#define MOPK_STAMP_PH 2
+#endif
+#define STAMP() do { if (PH == MOPK_STAMP_PH && blockIdx.x == 0 && tid == 0 && stamp_i < 60) stamps[stamp_i] = __builtin_amdgcn_s_memtime(); ++stamp_i; } while (0)
 #else
 #define STAMP() do { } while (0)
 #endif
