@@ -48,7 +48,6 @@ def _jobs():
         for nt in NTS:
             for dk in DKS:
                 jobs.append((s, fm + [f"-DMOPK_INST_NT={nt}", f"-DMOPK_INST_DK={dk}"], f"{stem}_nt{nt}_dk{dk}.o"))
-    jobs.append(("edgewise_fused16.hip", ["-ffast-math", "-fno-finite-math-only"], "edgewise_fused16.o"))
     return jobs
 
 

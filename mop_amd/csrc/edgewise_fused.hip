@@ -557,16 +557,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int g = 0; g < 16; ++g) L[g] = mx[g] + __logf(se[g]);   // lse_v S_v - S_0
         }
-        if (SAVE) {                       // L x log2(e) as packed fp16, accumulator order (the backward's S_L slab)
-            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-            u4 lo, hi;
+        if (SAVE) {                       // L x log2(e) in fp32, accumulator order (the backward's S_L slab: [wave][4 t + q][lane] x 16 B)
+            f32x4 *lp = (f32x4 *)(svb + SL.oL + (size_t)w * 2 * NT * 8 * 64 * 4) + lane;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                lo[p] = pack_h2(L[2 * p] * 1.4426950408889634f, L[2 * p + 1] * 1.4426950408889634f);
-                hi[p] = pack_h2(L[8 + 2 * p] * 1.4426950408889634f, L[8 + 2 * p + 1] * 1.4426950408889634f);
-            }
-            u4 *lp = (u4 *)(svb + SL.oL + (size_t)w * NT * 8 * 64 * 4) + lane;
-            __builtin_nontemporal_store(lo, &lp[(2 * t) * 64]); __builtin_nontemporal_store(hi, &lp[(2 * t + 1) * 64]);
+            for (int q = 0; q < 4; ++q)
+                __builtin_nontemporal_store(f32x4{L[4 * q], L[4 * q + 1], L[4 * q + 2], L[4 * q + 3]} * 1.4426950408889634f, &lp[(4 * t + q) * 64]);
         }
         // Smix = S0 + (G_and - nb G_not) O + G_or L + G_chain Cr, one gate at a time
         {
@@ -720,14 +715,8 @@ size_t ew_fused_saved_bytes(const MopkEdgewiseArgs *a) {
     switch (pick_nt(a->N)) { case 1: MOPK_DKS(1) case 2: MOPK_DKS(2) case 4: MOPK_DKS(4) case 7: MOPK_DKS(7) default: return 0; }
 #undef MOPK_DKS
 }
-int ew16_fwd_supported(const MopkEdgewiseArgs *a);
-int ew16_fwd(const MopkEdgewiseArgs *a, hipStream_t st);
-// MOPK_EW16=1 (read per call) routes the shapes it covers to the 16-query-wave forward instead: an experiment kept for A/B
-// timing -- at the bench shape it is 15-27 % slower than the 32-query kernel, so it is off by default
-static bool ew16_enabled() { const char *e = getenv("MOPK_EW16"); return e && e[0] == '1'; }
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
     if (!ew_fused_fwd_supported(a)) return MOPK_ERR_UNSUPPORTED;
-    if (ew16_enabled() && ew16_fwd_supported(a)) return ew16_fwd(a, st);     // same `saved` record, 16-query waves (edgewise_fused16.hip)
 #define MOPK_DK(NT_)                                                         \
     switch (a->dk) {                                                         \
         case 16: return ew_fused_fwd_nt##NT_##_dk16(a, st);                  \

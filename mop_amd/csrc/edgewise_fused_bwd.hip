@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     unsigned short *R = (unsigned short *)smem;                       // [NP][LDA] matrix region
     unsigned short *bT = R;                                           // [4][NP][BTS]           (mix phases)
     unsigned short *bmat = bT + 4 * NP * BTS;                         // [32][LDA] rows rho: b_hi (0-15) / b_lo (16-31), k-permuted cols
-    unsigned short *amat = bmat + 32 * LDA;                           // [32][LDA] rows rho: a_hi / a_lo, natural cols
+    unsigned short *amat = bmat + 32 * LDA;                           // [32][LDA] rows rho: a_hi / a_lo, k-permuted cols
     unsigned short *tbuf = amat + 32 * LDA;                           // [NT][32][40] per-wave 32x32 transpose buffer
     float *Wsm = (float *)(smem + Cfg::GATE_BYTES);                    // [2][16][19] gate-head weights (+bias at [18]) staged per (b,h) for P3..P7
     float *dav = (float *)R;                                          // [16][NP]  (after the mix-backward loop)
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             const unsigned short hi2 = f2bf(a2), lo2 = f2bf(a2 - bf2f(hi2));
             af4[g][k] = (short)hi2;
             af4[g][4 + k] = h == 0 ? (short)lo2 : (short)0;
-            if (h == 0) { amat[(4 * g + k) * LDA + qi] = qok ? hi : (unsigned short)0; amat[(16 + 4 * g + k) * LDA + qi] = qok ? lo : (unsigned short)0; }
+            if (h == 0) { const int col = 32 * w + 16 * (r >> 4) + kperm16(r & 15); amat[(4 * g + k) * LDA + col] = qok ? hi : (unsigned short)0; amat[(16 + 4 * g + k) * LDA + col] = qok ? lo : (unsigned short)0; }
         }
     }
     __syncthreads();
@@ -661,10 +661,15 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ================= P6: mix backward =================
     f32x16 daacc = zero16();
-    unsigned short *tb = tbuf + w * 32 * 40;
 #pragma nounroll
     for (int t = 0; t < NT; ++t) {
         f32x16 dS;                                   // dSmix tile
+        bf16x8 idl, idh;                              // B fragments of the 32 x 32 identity in the accumulator's k order (for the transposes below)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            idl[e] = (short)(r == tile_row(e, h) ? 0x3f80 : 0);          // bf16(1.0)
+            idh[e] = (short)(r == 16 + tile_row(e, h) ? 0x3f80 : 0);
+        }
         // this tile's q / dy fragments are (re)read from L2 in one batch: kept resident across the loop they are spilled and
         // every use (6 + 1 per tile) starts with its own exposed scratch reload
         bf16x8 qraw_t[KS], dyf_t[KS];
@@ -686,9 +691,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
               for (int g = 0; g < 16; ++g) gA[g] = fmaf(-nb, G2[g], gA[g]); }
             g1 = gate_tile(t, 1);
             bf16x8 qe[KS];
-            {
-                const u32x4 *p = slot(S_L);
-                lse = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), __builtin_nontemporal_load(&p[(2 * t + 1) * 64])) * 0.6931471805599453f;   // L = lse - S0 (parked * log2 e)
+            {   // L = lse - S0, exported by the forward in fp32 (x log2 e)
+                const f32x4 *p = (const f32x4 *)(svb + SL.oL + (size_t)w * 2 * Cfg::SLOT) + lane;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 l4 = __builtin_nontemporal_load(&p[(4 * t + q) * 64]);
+                    lse[4 * q] = l4[0] * 0.6931471805599453f; lse[4 * q + 1] = l4[1] * 0.6931471805599453f;
+                    lse[4 * q + 2] = l4[2] * 0.6931471805599453f; lse[4 * q + 3] = l4[3] * 0.6931471805599453f;
+                }
             }
             for (int v = 0; v < V; ++v) {
                 scale_frag(qe, qraw_t, sqk + v * DK);
@@ -736,11 +746,17 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 pack_tile_bf(bl, bh, c3);
                 u32x4 *p = slot(X_C3); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
             }
-            // da[rho, i] += sum_j bmat_g[rho][j] dZ^T[j, i]      (rows of gate g4 only)
-            bf16x8 zl, zh;
+            // gate-logit gradients enter two contractions over ~N^2 edges whose result is a small difference of large sums: dZ is
+            // split into a bf16 value and its bf16 remainder (as a and b already are), so the products are fp32-accurate
+            bf16x8 zl, zh, yl, yh;
             pack_tile_bf(zl, zh, dZ);
             {
-                const bool mine = ((r >> 2) & 3) == g4;           // rows 4g4..4g4+3 (hi) and 16+4g4.. (lo)
+                const f32x16 rem = dZ - unpack_tile_bf(zl, zh);
+                pack_tile_bf(yl, yh, rem);
+            }
+            const bool mine = ((r >> 2) & 3) == g4;               // rows 4g4..4g4+3 (hi) and 16+4g4.. (lo)
+            // da[rho, i] += sum_j bmat_g[rho][j] dZ^T[j, i]      (rows of gate g4 only)
+            {
                 bf16x8 a0 = {0, 0, 0, 0, 0, 0, 0, 0}, a1 = a0;
                 if (mine) {
                     a0 = *(const bf16x8 *)&bmat[r * LDA + 32 * t + 8 * h];
@@ -748,22 +764,29 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
                 daacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, zl, daacc, 0, 0, 0);
                 daacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, zh, daacc, 0, 0, 0);
+                daacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, yl, daacc, 0, 0, 0);
+                daacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, yh, daacc, 0, 0, 0);
             }
-            // db[rho, j] (this wave's queries) = sum_i amat_g[rho][i] dZ[i, j] : transpose the tile through LDS
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                tb[tile_row(g, h) * 40 + r] = (unsigned short)zl[g];
-                tb[tile_row(8 + g, h) * 40 + r] = (unsigned short)zh[g];
-            }
+            // db[rho, j] (keys of tile t) = sum_i amat_g[rho][i] dZ[i, j]: the contraction runs over this wave's queries (= lanes), so
+            // the tile is transposed on the matrix core (X . I: lane = key, registers = queries; exact for bf16 values) and its packed
+            // halves are the B fragments in the accumulator's k order -- amat's columns are stored in that order
             {
-                const bool mine = ((r >> 2) & 3) == g4;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    bf16x8 aa = {0, 0, 0, 0, 0, 0, 0, 0};
-                    if (mine) aa = *(const bf16x8 *)&amat[r * LDA + 32 * w + 16 * s + 8 * h];
-                    const bf16x8 bb = *(const bf16x8 *)&tb[r * 40 + 16 * s + 8 * h];
-                    dbt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, dbt, 0, 0, 0);
+                bf16x8 aa0 = {0, 0, 0, 0, 0, 0, 0, 0}, aa1 = aa0;
+                if (mine) {
+                    aa0 = *(const bf16x8 *)&amat[r * LDA + 32 * w + 8 * h];
+                    aa1 = *(const bf16x8 *)&amat[r * LDA + 32 * w + 16 + 8 * h];
                 }
+                f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zl, idl, zero16(), 0, 0, 0);
+                tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zh, idh, tr, 0, 0, 0);
+                bf16x8 tl, th;
+                pack_tile_bf(tl, th, tr);
+                dbt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa0, tl, dbt, 0, 0, 0);
+                dbt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa1, th, dbt, 0, 0, 0);
+                tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, idl, zero16(), 0, 0, 0);
+                tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, idh, tr, 0, 0, 0);
+                pack_tile_bf(tl, th, tr);
+                dbt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa0, tl, dbt, 0, 0, 0);
+                dbt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa1, th, dbt, 0, 0, 0);
             }
         }
         // dbt rows rho (hi: regs 0-7, lo: regs 8-15), lanes = keys of tile t

@@ -130,10 +130,11 @@ __host__ __device__ inline FusedSavedLayout fused_saved_layout(int N, int V, boo
         L.oCB = o; o += a256(NT * WSLOT);
         L.oCst = o; o += a256((size_t)V * NP * 4);
         L.oMeans = o; o += a256((size_t)4 * NP * 4);
-        // mixed logits Smix and L = lse_v S_v - S_0 (x log2 e) as packed fp16 per-wave slabs, final-softmax row max / 1 / row sum:
+        // mixed logits Smix as a packed fp16 per-wave slab, L = lse_v S_v - S_0 (x log2 e) as an fp32 slab (it multiplies the OR gate's
+        // gradient edge by edge: rounded to fp16 it alone put 2-5 % on the gate-head weight gradients), final-softmax row max / 1 / row sum:
         // with these the backward has no mix-recompute pass
         L.oSm = o; o += a256(NT * WSLOT);
-        L.oL = o; o += a256(NT * WSLOT);
+        L.oL = o; o += a256(2 * NT * WSLOT);
         L.oRow = o; o += a256((size_t)2 * NP * 4);
         L.oYb = o; o += a256((size_t)N * DK * 4);      // y_base = P v0 (fp32): delta_i = sum_j P_ij dP_ij = dy_i . y_base_i
     }

@@ -26,3 +26,10 @@ def load_golden(name):
     grads = {k[5:]: v for k, v in d.items() if k.startswith("grad:")}
     meta = {k[5:]: (v.item() if v.ndim == 0 else v) for k, v in d.items() if k.startswith("meta:")}
     return d, params, grads, meta
+
+
+def ref_bf16_error(d, key):
+    """max-abs error / max|fp32| of the REFERENCE's own all-bfloat16 run against its float32 run for gradient `key` ('dx' or a
+    parameter name), recorded by tools/gen_golden.py; 0.0 when the fixture does not carry it."""
+    v = d.get("bf16err:" + key)
+    return float(v) if v is not None else 0.0

@@ -5,13 +5,13 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_names, load_golden
-from gpu_util import check_grads, max_abs, module_from_golden, rel_err, run_fwd_bwd
+from conftest import golden_names, load_golden, ref_bf16_error
+from gpu_util import check_grads, max_abs, module_from_golden, oracle_bf16_noise, rel_err, run_fwd_bwd
 
 pytestmark = pytest.mark.gpu
 
 TOL_FP32, TOL_BF16 = 1e-3, 1e-2          # max-abs on y (north_star)
-GTOL_FP32, GTOL_BF16 = 1e-3, 1.5e-1        # gradients: max-abs / max|ref| (bf16 bound is ours; north_star bounds y only)
+GTOL_FP32, GTOL_BF16 = 1e-3, 3e-2          # gradients: max-abs / max|ref| (bf16 bound is ours; north_star bounds y only)
 
 
 def _ctor(meta):
@@ -44,9 +44,11 @@ def test_edgewise_vs_reference_golden(name, prec, path):
     assert max_abs(y, d["y"]) <= tol, f"y max-abs {max_abs(y, d['y']):.3e}"
     assert rel_err(dx, d["dx"]) <= gtol, f"dx rel {rel_err(dx, d['dx']):.3e}"
     assert set(grads) == set(gref)
-    for k in gref:
-        assert rel_err(grads[k].reshape(gref[k].shape), gref[k]) <= gtol, \
-            f"grad {k}: rel {rel_err(grads[k].reshape(gref[k].shape), gref[k]):.3e}"
+    if prec == "fp32":
+        for k in gref:
+            assert rel_err(grads[k].reshape(gref[k].shape), gref[k]) <= gtol, f"grad {k}: rel {rel_err(grads[k].reshape(gref[k].shape), gref[k]):.3e}"
+    else:       # 3e-2 per tensor, or 3 x the error of the REFERENCE's own all-bf16 run where bf16 cannot resolve the tensor (gpu_util.check_grads)
+        check_grads(grads, gref, gtol, d=d)
 
 
 def _ctor_variant(meta):
@@ -74,7 +76,7 @@ def test_edgewise_variants_vs_reference_golden(name, prec):
     tol, gtol = (TOL_FP32, GTOL_FP32) if prec == "fp32" else (TOL_BF16, GTOL_BF16)
     assert max_abs(y, d["y"]) <= tol, f"y max-abs {max_abs(y, d['y']):.3e}"
     assert rel_err(dx, d["dx"]) <= gtol, f"dx rel {rel_err(dx, d['dx']):.3e}"
-    check_grads(grads, gref, gtol, floor=1e-3 if prec == "fp32" else 1e-2)
+    check_grads(grads, gref, gtol, floor=1e-3 if prec == "fp32" else 1e-2, d=d if prec == "bf16" else None)
     if meta["gate_mode"] == "dense" or meta["use_lens_bank"]:
         assert ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_GENERIC
 
@@ -117,7 +119,8 @@ def test_bf16_tensors_end_to_end():
     m = module_from_golden(EdgewiseMSA, params, **_ctor(meta))
     y, dx, grads = run_fwd_bwd(m, d["x"], d["w"], dtype=torch.bfloat16)
     assert max_abs(y, d["y"]) <= TOL_BF16
-    assert rel_err(dx, d["dx"]) <= 5e-2
+    assert rel_err(dx, d["dx"]) <= 3e-2
+    check_grads(grads, gref, GTOL_BF16, d=d)
 
 
 def test_cpu_tensor_fails_loudly():
@@ -205,39 +208,11 @@ def test_fused_vs_oracle_shape_sweep(shape):
     y, dx, grads = run_fwd_bwd(m.cuda().eval(), x, w)
     assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED and ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_FUSED
     assert max_abs(y, out) <= TOL_BF16
-    assert rel_err(dx, dx_ref) <= 5e-2
-    # floor 2e-3: at (1,129,128,2,3,1) the rank-1 row_proj gradient is 1e-4 of the module's scale and pure bf16
-    # cancellation noise (the generic bf16 path is 40% off on it too); it is judged against the module scale instead
-    check_grads(grads, g_ref, GTOL_BF16, scalar_tol=0.5, floor=2e-3)
-
-
-@pytest.mark.parametrize("shape", [(1, 129, 128, 2, 3, 1), (2, 197, 128, 2, 5, 4), (1, 224, 64, 1, 5, 4), (2, 150, 64, 2, 4, 2)])
-def test_forward_with_16_query_waves_matches_the_default_kernel_and_feeds_the_backward(shape, monkeypatch):
-    """MOPK_EW16=1 swaps in the 16-query-wave forward (edgewise_fused16.hip) for 128 < N <= 224, dk 32/64: its output must
-    match the oracle like the default kernel's, and the chain state it exports must drive the (32-query) backward to the
-    same gradients."""
-    from oracle import edgewise as oe
-    import mop_amd
-    from mop_amd import ops, _lib
-    B, N, D, H, V, r = shape
-    mop_amd.set_precision("bf16")
-    m = _mk(D, H, V, r, seed=B * 1000 + N)
-    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
-    g = torch.Generator().manual_seed(N)
-    x = torch.randn(B, N, D, generator=g).numpy()
-    w = torch.randn(B, N, D, generator=g).numpy()
-    out, cache = oe.module_fwd(x.astype(np.float64), params, H, V, True, 0.5)
-    dx_ref, g_ref = oe.module_bwd(w.astype(np.float64), cache)
-    m = m.cuda().eval()
-    y0, dx0, grads0 = run_fwd_bwd(m, x, w)
-    monkeypatch.setenv("MOPK_EW16", "1")
-    m.zero_grad(set_to_none=True)
-    y1, dx1, grads1 = run_fwd_bwd(m, x, w)
-    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED
-    assert max_abs(y1, out) <= TOL_BF16
-    assert max_abs(y1, y0) <= 4e-3            # two bf16 evaluation orders of the same maps
-    assert rel_err(dx1, dx_ref) <= 5e-2
-    check_grads(grads1, g_ref, GTOL_BF16, scalar_tol=0.5, floor=2e-3)
+    assert rel_err(dx, dx_ref) <= 3e-2
+    # per tensor: 3e-2, or 4 x the amount the exact (float64) gradient itself moves when the inputs are rounded to bf16 -- e.g. at
+    # (1,129,128,2,3,1) the rank-1 row_proj gradient is 1e-4 of the module's scale and pure cancellation noise in any bf16 arithmetic
+    noise = oracle_bf16_noise(oe.module_fwd, oe.module_bwd, x, w, params, H, V, True, 0.5)
+    check_grads(grads, g_ref, GTOL_BF16, d=noise)
 
 
 def test_shapes_outside_the_fused_kernels_take_the_generic_path():

@@ -8,7 +8,7 @@ from conftest import golden_names, load_golden
 from gpu_util import check_grads, max_abs, module_from_golden, rel_err, run_fwd_bwd
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp32": (1e-3, 1e-3), "bf16": (1e-2, 1.5e-1)}
+TOL = {"fp32": (1e-3, 1e-3), "bf16": (1e-2, 3e-2)}
 
 
 @pytest.fixture(autouse=True)
@@ -22,7 +22,8 @@ def _check(y, dx, grads, d, gref, prec):
     tol, gtol = TOL[prec]
     assert max_abs(y, d["y"]) <= tol, f"y {max_abs(y, d['y']):.3e}"
     assert rel_err(dx, d["dx"]) <= gtol, f"dx {rel_err(dx, d['dx']):.3e}"
-    check_grads(grads, gref, gtol, scalar_tol=0.5 if prec == "bf16" else None, floor=1e-2 if prec == "bf16" else 1e-3)
+    check_grads(grads, gref, gtol, scalar_tol=5e-2 if prec == "bf16" else None, floor=1e-2 if prec == "bf16" else 1e-3,
+                d=d if prec == "bf16" else None)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
@@ -154,7 +155,7 @@ def test_whisper_encoder_block(name, prec):
     tol, gtol = TOL[prec]
     assert max_abs(y, d["y"]) / float(np.abs(d["y"]).max()) <= tol
     assert rel_err(dx, d["dx"]) <= gtol
-    check_grads(grads, gref, gtol, floor=1e-2 if prec == "bf16" else 1e-3)
+    check_grads(grads, gref, gtol, floor=1e-2 if prec == "bf16" else 1e-3, d=d if prec == "bf16" else None)
 
 
 def test_whisper_self_attention_causal_bias_matches_torch():

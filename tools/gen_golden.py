@@ -53,7 +53,26 @@ def _perturb(mod: torch.nn.Module, seed: int):
                 p.fill_(-0.5)
 
 
-def _run(mod, x, fwd_kwargs=None, extra=None, hook=None):
+def _bf16_self_error(mod, x, w, fwd_kwargs, ref):
+    """The reference module run end to end in bfloat16 (parameters, input, every op) against its own float32 run: max-abs error /
+    max|fp32 value| per gradient tensor ('bf16err:<name>').  The bf16 parity tests use it as the noise floor of bf16 arithmetic on
+    this case: an implementation cannot be asked to be closer to the fp32 gradients than the reference's own bf16 run is."""
+    import copy
+    mb = copy.deepcopy(mod).to(torch.bfloat16)
+    xb = x.detach().clone().to(torch.bfloat16).requires_grad_(True)
+    fwd_kwargs = {k: (v.to(torch.bfloat16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in fwd_kwargs.items()}
+    yb = mb(xb, **fwd_kwargs)
+    (yb * w.to(torch.bfloat16)).sum().backward()
+    rel = lambda a, b: float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    out = {"bf16err:y": np.float32(np.abs(yb.detach().float().numpy() - ref["y"]).max()),
+           "bf16err:dx": np.float32(rel(xb.grad.float().numpy(), ref["dx"]))}
+    for k, p in mb.named_parameters():
+        if p.grad is not None:
+            out["bf16err:" + k] = np.float32(rel(p.grad.float().numpy(), ref["grad:" + k]))
+    return out
+
+
+def _run(mod, x, fwd_kwargs=None, extra=None, hook=None, bf16_self=False):
     fwd_kwargs = fwd_kwargs or {}
     x = x.clone().requires_grad_(True)
     inter = {}
@@ -70,6 +89,8 @@ def _run(mod, x, fwd_kwargs=None, extra=None, hook=None):
     if extra:
         out.update(extra)
     out.update(inter)
+    if bf16_self:
+        out.update(_bf16_self_error(mod, x, w, fwd_kwargs, out))
     return out
 
 
@@ -100,7 +121,7 @@ def edgewise_cases():
         meta = dict(kind="edgewise", dim=dim, heads=heads, beta_not=kw.get("beta_not", 0.5),
                     n_views=kw["n_views"], share_qkv=kw["share_qkv"], gate_rank=kw["gate_rank"])
         extra = {"meta:" + k: np.asarray(v) for k, v in meta.items()}
-        _save(name, _run(mod, x, extra=extra))
+        _save(name, _run(mod, x, extra=extra, bf16_self=True))
 
 
 def edgewise_variant_cases():
@@ -135,7 +156,7 @@ def edgewise_variant_cases():
                     lens_qk_dilations=np.asarray(kw.get("lens_qk_dilations", ()), dtype=np.int64),
                     lens_qk_causal=kw.get("lens_qk_causal", False))
         extra = {"meta:" + k: np.asarray(v) for k, v in meta.items()}
-        _save(name, _run(mod, x, extra=extra))
+        _save(name, _run(mod, x, extra=extra, bf16_self=True))
 
 
 def crossview_cases():
@@ -170,7 +191,7 @@ def crossview_cases():
             with torch.no_grad():                                 # the anchor the reference picked (:139-140), rounding-noise dependent
                 _, _, S2, _ = mod._compute_logits(x)
                 extra["k_star"] = torch.softmax(mod._apply_mask(S2, fk.get("attn_mask")), -1).sum(-1).argmax(-1).numpy()
-        _save(name, _run(mod, x, fk, extra))
+        _save(name, _run(mod, x, fk, extra, bf16_self=True))
 
 
 def whisper_cases():
@@ -221,7 +242,7 @@ def multihop_cases():
                     hops=kw.get("hops", 3), g_and=g["and_"], g_or=g["or_"], g_not=g["not_"],
                     g_chain=g["chain"])
         extra.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
-        _save(name, _run(mod, x, fk, extra))
+        _save(name, _run(mod, x, fk, extra, bf16_self=True))
 
 
 def quartet_cases():
@@ -245,7 +266,7 @@ def quartet_cases():
             extra["attention_mask"] = am.numpy()
         meta = dict(kind="quartet", dim=dim, heads=heads, use_quartet=uq, eps=cfg.score_norm_eps)
         extra.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
-        _save(name, _run(mod, x, fk, extra))
+        _save(name, _run(mod, x, fk, extra, bf16_self=True))
 
 
 def sdpa_cases():
@@ -262,7 +283,7 @@ def sdpa_cases():
             extra["attn_mask"] = mask.numpy()
         meta = dict(kind="sdpa", dim=dim, heads=heads)
         extra.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
-        _save(name, _run(mod, x, fk, extra))
+        _save(name, _run(mod, x, fk, extra, bf16_self=True))
 
 
 if __name__ == "__main__":
