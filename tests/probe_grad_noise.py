@@ -6,7 +6,7 @@ the kernels round it, and prints max-abs error / max|ref| for dWr, dWc.  The las
 scaled queries Qe = bf16(q * sqk)): that error is shared by every bf16-input implementation, the reference's own bf16 run included."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # run as: python tests/probe_grad_noise.py (lives under tests/: it imports the oracle)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden
 from oracle import edgewise as oe
