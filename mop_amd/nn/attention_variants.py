@@ -39,23 +39,30 @@ _LOWRANK_PRESET = {
 _DENSE_PRESET = {"and": 0, "or": 1, "not": 2, "nor": 2, "xor": 1, "chain": 3}   # :259-272
 
 
-_CAUSAL_CACHE: Dict[Tuple[int, int, Tuple[int, ...]], bool] = {}
+_CAUSAL_CACHE: Dict[int, tuple] = {}  # id(mask) -> (weakref to the mask tensor, version, is_causal)
 
 
 def _is_causal_mask(mask: Optional[torch.Tensor], n: int) -> bool:
     """True iff `mask` (0 = blocked) is exactly the lower-triangular causal mask shared by every batch and head.
-    The comparison runs once per mask tensor version (it synchronises)."""
+
+    The comparison synchronises, so its result is cached per mask TENSOR OBJECT and version: an entry holds a weak reference to the
+    tensor and counts only while that very object is alive (never keyed by the data address -- the caching allocator hands a freed
+    mask's address to the next mask of the same shape), and it is re-validated whenever the tensor was written in place."""
+    import weakref
     if mask is None or mask.shape[-2:] != (n, n) or any(d != 1 for d in mask.shape[:-2]):
         return False
-    key = (mask.data_ptr(), mask._version, tuple(mask.shape))
-    hit = _CAUSAL_CACHE.get(key)
-    if hit is None:
+    hit = _CAUSAL_CACHE.get(id(mask))
+    if hit is None or hit[0]() is not mask or hit[1] != mask._version:
         tri = torch.ones(n, n, dtype=torch.bool, device=mask.device).tril_()
-        hit = bool(torch.equal(mask.reshape(n, n) != 0, tri))
+        verdict = bool(torch.equal(mask.reshape(n, n) != 0, tri))
         if len(_CAUSAL_CACHE) > 64:
-            _CAUSAL_CACHE.clear()
-        _CAUSAL_CACHE[key] = hit
-    return hit
+            for k in [k for k, v in _CAUSAL_CACHE.items() if v[0]() is None]:
+                del _CAUSAL_CACHE[k]
+            if len(_CAUSAL_CACHE) > 64:
+                _CAUSAL_CACHE.clear()
+        hit = (weakref.ref(mask), mask._version, verdict)
+        _CAUSAL_CACHE[id(mask)] = hit
+    return hit[2]
 
 
 class EdgewiseGateHead(nn.Module):
@@ -240,6 +247,8 @@ class BaselineMSA(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.training and self.attn_drop.p > 0:       # reference :45 applies dropout to the attention weights
+            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
         B, N, D = x.shape
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
         causal = _is_causal_mask(attn_mask, N)      # tril mask -> in-kernel causal flag (keeps the call on the fused kernels)
@@ -266,6 +275,8 @@ class MultiHopMSA(nn.Module):
         self.chain_value_logit = nn.Parameter(torch.tensor(-2.0))
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.training and self.attn_drop.p > 0:       # reference :222 applies dropout to the mixed attention weights
+            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
         B, N, D = x.shape
         qkv1 = self.qkv1(x).view(B, N, 3, self.h, self.dk)
         qkv2 = self.qkv2(x).view(B, N, 3, self.h, self.dk)

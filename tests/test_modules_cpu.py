@@ -94,6 +94,34 @@ def test_unsupported_variants_raise_instead_of_falling_back():
         EdgewiseMSA(64, 4, gate_mode="dense")(x)
 
 
+def test_attention_dropout_in_training_raises_in_every_module():
+    """the reference applies attn_drop to the attention weights (attention_variants.py:45, :153, :222, :552); the kernels do not,
+    so every module refuses the configuration instead of silently training a different model."""
+    from mop_amd.nn import BaselineMSA, CrossViewMixerMSA, EdgewiseMSA, MultiHopMSA
+    x = torch.randn(1, 8, 64)
+    for cls, kw in ((BaselineMSA, {}), (MultiHopMSA, {}), (CrossViewMixerMSA, {}),
+                    (EdgewiseMSA, dict(gate_mode="lowrank", share_qkv=True))):
+        m = cls(64, 4, attn_drop=0.1, **kw).train()
+        with pytest.raises(NotImplementedError, match="attn_drop"):
+            m(x)
+
+
+def test_causal_mask_detection_is_keyed_by_tensor_identity_not_address():
+    """a non-causal mask allocated at the address of a freed causal one must not inherit its cached verdict"""
+    from mop_amd.nn.attention_variants import _is_causal_mask
+    n = 16
+    verdicts = []
+    for i in range(8):                       # same shape, alternating content; CPU allocations are recycled as freely as device ones
+        m = torch.ones(1, 1, n, n).tril_() if i % 2 == 0 else torch.ones(1, 1, n, n)
+        verdicts.append(_is_causal_mask(m, n))
+        del m
+    assert verdicts == [True, False] * 4
+    m = torch.ones(n, n).tril_()
+    assert _is_causal_mask(m, n)
+    m[0, n - 1] = 1                           # in-place edit bumps the version: re-validated
+    assert not _is_causal_mask(m, n)
+
+
 @pytest.mark.parametrize("kw", [
     dict(gate_mode="dense", use_k3=True, n_views=3, share_qkv=True),
     dict(gate_mode="lowrank", gate_rank=2, n_views=3, share_qkv=True, use_lens_bank=True, lens_dilations=(1, 2)),
