@@ -52,25 +52,68 @@ def build_layer(dtype):
     return m.cuda().to(dtype)
 
 
-def cpu_baseline(sample_b=32, reps=5):
-    """The numpy oracle (a port of the reference path) timed on this box's host cores."""
+def host_cores():
+    """CPU cores this process may actually use: min(logical CPUs, affinity mask, cgroup CPU quota).  On the GPU box a 1-GPU lease is a
+    16-CPU share of a 256-thread host (cgroup cpu.max = 1600000/100000); 256 torch threads under that quota run 70 x slower than 16."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(sample_b=16, reps=5, warm=2):
+    """The reference path restated for the CPU (oracle/edgewise_torch.py, pinned against the reference fixtures), timed on this
+    box's host cores as SURVEY.md section 8(d) specifies: torch CPU ops on all cores this process may use (host_cores()), B = 16 images,
+    forward + autograd backward,
+    median of `reps` after `warm` warm-ups.  The numpy oracle (single-threaded algebra + BLAS) is timed beside it."""
     import numpy as np
     from oracle import edgewise as oe
-    m = build_layer_cpu()
+    from oracle import edgewise_torch as oet
+    cores = host_cores()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        m = build_layer_cpu()
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(sample_b, NS["N"], NS["D"], generator=g).requires_grad_(True)
+        w = torch.randn(sample_b, NS["N"], NS["D"], generator=g)
+        ts = []
+        for i in range(warm + reps):
+            for t in list(p.values()) + [x]:
+                t.grad = None
+            t0 = time.perf_counter()
+            y = oet.edgewise_layer(x, p, NS["H"], NS["V"], 0.5)
+            (y * w).sum().backward()
+            ts.append(time.perf_counter() - t0)
+        t_torch = sorted(ts[warm:])[reps // 2]
+    finally:
+        torch.set_num_threads(prev)
+    # second figure: the numpy oracle (what the parity tests run), one warm-up, median of 3
     params = {k: v.detach().numpy() for k, v in m.state_dict().items()}
-    rng = np.random.default_rng(0)
-    x = rng.standard_normal((sample_b, NS["N"], NS["D"]), dtype=np.float32)
-    w = rng.standard_normal((sample_b, NS["N"], NS["D"]), dtype=np.float32)
-    ts = []
-    for i in range(reps + 1):
+    xn, wn = x.detach().numpy(), w.numpy()
+    tn = []
+    for i in range(4):
         t0 = time.perf_counter()
-        out, cache = oe.module_fwd(x, params, NS["H"], NS["V"], True, 0.5)
-        oe.module_bwd(w, cache)
-        ts.append(time.perf_counter() - t0)
-    t = sorted(ts[1:])[len(ts[1:]) // 2]
-    return dict(value=sample_b / t, unit="images/s", cores=os.cpu_count(), kind="port",
-                sample=f"oracle/edgewise.py module_fwd+module_bwd, float32, B={sample_b} images, "
-                       f"median of {reps} after 1 warm-up ({t:.2f} s per pass)")
+        out, cache = oe.module_fwd(xn, params, NS["H"], NS["V"], True, 0.5)
+        oe.module_bwd(wn, cache)
+        tn.append(time.perf_counter() - t0)
+    t_np = sorted(tn[1:])[1]
+    return dict(value=sample_b / t_torch, unit="images/s", cores=cores, kind="port",
+                sample=f"oracle/edgewise_torch.py (torch CPU restatement, means-only formulation) fwd+bwd, float32, "
+                       f"torch.set_num_threads({cores}), B={sample_b} images, median of {reps} after {warm} warm-ups "
+                       f"({t_torch:.3f} s per pass)",
+                numpy_oracle={"value": sample_b / t_np, "unit": "images/s",
+                              "sample": f"oracle/edgewise.py module_fwd+module_bwd, float32, B={sample_b}, median of 3 after 1 warm-up "
+                                        f"({t_np:.2f} s per pass); BLAS threads as numpy defaults"})
 
 
 def build_layer_cpu():
@@ -87,6 +130,25 @@ def build_layer_cpu():
     return m
 
 
+VIT = dict(dim=384, depth=3, heads=6, n_classes=100, img=32)      # BASELINE.json configs[2]: ViT-MoP ~5.4 M parameters
+
+
+def _self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start one fresh process per GPU through
+    torch.distributed.run (this process has not touched the GPU), relay rank 0's JSON line and exit with the children's status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL / tensor sharing across processes)
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,41 +156,65 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=NS["B"], help="per-GPU batch (default = BASELINE config)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="layer", choices=["layer", "vit"],
+                    help="layer: one EdgewiseMSA layer fwd+bwd (BASELINE.json configs[1], the metric's workload at every N); "
+                         "vit: ViT-MoP 5.4 M training step with AdamW (configs[2], 256 images per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the multi-process protocol on CPU (gloo): rendezvous, one flat gradient all-reduce per step, "
+                         "barrier + max-over-ranks timing, rank-0 JSON; no GPU work, the value is not a measurement")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); they must agree")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist = None
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from mop_amd import ops
+    from mop_amd.parallel import FlatGradBucket
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    layer = build_layer(dtype)
-    params = [p for p in layer.parameters()]
     B = args.batch
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
-    x = torch.randn(B, NS["N"], NS["D"], device="cuda", dtype=dtype, generator=g).requires_grad_(True)
-    dy = torch.randn(B, NS["N"], NS["D"], device="cuda", dtype=dtype, generator=g)
-    from mop_amd.parallel import FlatGradBucket
-    bucket = FlatGradBucket(params)
+    if args.workload == "layer":
+        layer = build_layer(dtype)
+        params = [p for p in layer.parameters()]
+        x = torch.randn(B, NS["N"], NS["D"], device="cuda", dtype=dtype, generator=g).requires_grad_(True)
+        dy = torch.randn(B, NS["N"], NS["D"], device="cuda", dtype=dtype, generator=g)
+        bucket = FlatGradBucket(params)
 
-    def step():
-        for p in params:
-            p.grad = None
-        x.grad = None
-        y = layer(x)
-        y.backward(dy)
-        if world > 1:  # one flat gradient bucket, one RCCL all-reduce over xGMI
-            bucket.allreduce_(average=True)
+        def step():
+            for p in params:
+                p.grad = None
+            x.grad = None
+            y = layer(x)
+            y.backward(dy)
+            if world > 1:  # one flat gradient bucket, one RCCL all-reduce over xGMI
+                bucket.allreduce_(average=True)
+    else:
+        import torch.nn.functional as F
+        from mop_amd.nn import ViT_MoP
+        from mop_amd.training import DataParallelStep, make_optimizer_and_schedule
+        torch.manual_seed(0)                           # identical initial weights on every rank
+        model = ViT_MoP(dim=VIT["dim"], depth=VIT["depth"], heads=VIT["heads"], n_classes=VIT["n_classes"], drop_path=0.0).cuda().to(dtype)
+        opt, sched = make_optimizer_and_schedule(model, 3e-3, 5e-2, steps=max(args.steps + args.warmup + 1, 2))
+        dp = DataParallelStep(model, opt, lambda out, tgt: F.cross_entropy(out.float(), tgt), sched)   # flat all-reduce inside
+        params = [p for p in model.parameters()]
+        xi = torch.randn(B, 3, VIT["img"], VIT["img"], device="cuda", generator=g).to(dtype)
+        yi = torch.randint(0, VIT["n_classes"], (B,), device="cuda", generator=g)
+
+        def step():
+            dp(xi, yi)
 
     # one untimed initialisation pass (code-object loading, hipBLASLt kernel selection by TunableOp, allocator growth), so that the
     # W warm-up steps -- and with --warmup 0 the timed steps -- run the steady-state path
@@ -155,46 +241,103 @@ def main():
     ops.enable_timing(False)
 
     if rank == 0:
-        import ctypes as C
-        from mop_amd import _lib as L
-        a = L.EdgewiseArgs()
-        a.B, a.H, a.N, a.dk, a.V, a.r = B, NS["H"], NS["N"], NS["D"] // NS["H"], NS["V"], NS["r"]
-        a.precision = L.PREC_BF16 if args.dtype == "bf16" else L.PREC_FP32
-        a.io_dtype = L.MOPK_BF16 if args.dtype == "bf16" else L.MOPK_F32
-        a.path = ops.LAST_PATH.get("edgewise_bwd", L.PATH_AUTO)
-        dom_bwd = L.lib().mopk_edgewise_dominant_kernel(C.byref(a), 1).decode()
-        traffic = None  # HBM bytes per launch from rocprofv3 PMC passes (profiles/*hbm_traffic.json), if collected
-        tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tpath) and B == NS["B"]:
-            traffic = json.load(open(tpath)).get(dom_bwd, {}).get("hbm_bytes_per_launch")
-        fwd_ms = sum(tim.get("edgewise_fwd", [0.0])) / max(1, len(tim.get("edgewise_fwd", [])))
-        bwd_ms = sum(tim.get("edgewise_bwd", [0.0])) / max(1, len(tim.get("edgewise_bwd", [])))
-        # dominant launch = the backward core (2/3 of the algorithmic FLOPs)
-        ach = B * CORE_FLOP_BWD / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
-        ach_fwd = B * CORE_FLOP_FWD / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
         imgs = B * world * args.steps / dt
         out = {
             "metric": "MoP-attention fwd+bwd images/sec", "value": imgs, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "EdgewiseMSA layer fwd+bwd (qkv GEMM + libmopk attention core + proj GEMM), "
-                                   "BASELINE.json configs[1] shape", "per_gpu_batch": B, "tokens": NS["N"],
-                       "dim": NS["D"], "heads": NS["H"], "views": NS["V"], "gate_rank": NS["r"],
-                       "share_qkv": True, "gate_mode": "lowrank",
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "kernel": dom_bwd, "achieved": ach, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
-                         "launch_ms": bwd_ms, "algorithmic_flop_per_launch": B * CORE_FLOP_BWD,
-                         "fwd": {"launch_ms": fwd_ms, "achieved": ach_fwd, "frac": ach_fwd / PEAK_BF16_TFLOPS},
-                         "core_fwd_bwd_frac": (B * (CORE_FLOP_FWD + CORE_FLOP_BWD) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
-                                               / PEAK_BF16_TFLOPS) if fwd_ms + bwd_ms > 0 else 0.0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        par = f"dp{world}" if world > 1 else "single"
+        if args.workload == "layer":
+            out["config"] = {"workload": "EdgewiseMSA layer fwd+bwd (qkv GEMM + libmopk attention core + proj GEMM), "
+                                         "BASELINE.json configs[1] shape", "per_gpu_batch": B, "tokens": NS["N"],
+                             "dim": NS["D"], "heads": NS["H"], "views": NS["V"], "gate_rank": NS["r"],
+                             "share_qkv": True, "gate_mode": "lowrank", "parallelism": par,
+                             "grad_allreduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0}
+            out["roofline"] = roofline(tim, B, args.dtype)
+        else:
+            out["metric"] = "ViT-MoP 5.4M training images/sec"
+            out["config"] = {"workload": "ViT_MoP(dim 384, depth 3, heads 6, 100 classes) training step on 32x32 images: fwd + bwd + "
+                                         "one flat gradient all-reduce + AdamW (BASELINE.json configs[2])", "per_gpu_batch": B,
+                             "params": sum(p.numel() for p in params), "parallelism": par,
+                             "grad_allreduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def roofline(tim, B, dtype):
+    """MFMA roofline of the dominant pass -- the Edgewise backward core, three launches of ew_fused_bwd_kernel (template parameter
+    0 / 1 / 2: mix backward, D-chains, per-view gradients; their rocprofv3 kernel-trace averages add up to `launch_ms`) -- from HIP
+    events on the launch stream; `traffic` = fabric bytes of those launches from the committed PMC passes (profiles/)."""
+    fwd_ms = sum(tim.get("edgewise_fwd", [0.0])) / max(1, len(tim.get("edgewise_fwd", [])))
+    bwd_ms = sum(tim.get("edgewise_bwd", [0.0])) / max(1, len(tim.get("edgewise_bwd", [])))
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    if os.path.exists(tpath) and B == NS["B"] and dtype == "bf16":
+        tj = json.load(open(tpath))
+        traffic = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in tj.items() if "ew_fused_bwd_kernel" in k) or None
+    ach = B * CORE_FLOP_BWD / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+    ach_fwd = B * CORE_FLOP_FWD / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": "ew_fused_bwd_kernel<.., 0|1|2> (backward core: 3 launches)", "achieved": ach,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "launch_ms": bwd_ms, "algorithmic_flop_per_launch": B * CORE_FLOP_BWD,
+            "fwd": {"kernel": "ew_fused_fwd_kernel", "launch_ms": fwd_ms, "achieved": ach_fwd, "frac": ach_fwd / PEAK_BF16_TFLOPS},
+            "core_fwd_bwd_frac": (B * (CORE_FLOP_FWD + CORE_FLOP_BWD) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+                                  / PEAK_BF16_TFLOPS) if fwd_ms + bwd_ms > 0 else 0.0}
+
+
+def dry_run(args, world, rank):
+    """CPU rehearsal of the N-rank protocol (tests/test_dist_gloo.py): gloo rendezvous on 127.0.0.1, per step one flat all-reduce of
+    a gradient bucket of the workload's real size, barrier + max-over-ranks timing, rank 0 prints the JSON line."""
+    import torch.distributed as dist
+    from mop_amd.parallel import FlatGradBucket
+    if world > 1:
+        dist.init_process_group("gloo")
+    if args.workload == "layer":
+        model = build_layer_cpu()
+    else:
+        from mop_amd.nn import ViT_MoP
+        torch.manual_seed(0)
+        model = ViT_MoP(dim=VIT["dim"], depth=VIT["depth"], heads=VIT["heads"], n_classes=VIT["n_classes"], drop_path=0.0)
+    params = [p for p in model.parameters()]
+    bucket = FlatGradBucket(params)
+    g = torch.Generator().manual_seed(1234 + rank)
+
+    def step():
+        for p in params:                               # stand-in for forward/backward: rank-dependent synthetic gradients
+            p.grad = torch.full_like(p, float(rank + 1))
+        bucket.allreduce_(average=True)
+
+    for _ in range(args.warmup + 1):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    expect = (world + 1) / 2.0                          # mean of 1..world
+    ok = all(bool(torch.allclose(p.grad, torch.full_like(p, expect))) for p in params)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (no GPU work)", "value": args.batch * world * args.steps / dt, "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "dry-run",
+                          "config": {"workload": args.workload, "backend": "gloo", "parallelism": f"dp{world}",
+                                     "grad_allreduce_bytes": 4 * sum(p.numel() for p in params), "allreduce_ok": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("dry-run: averaged gradients differ from the expected mean")
 
 
 if __name__ == "__main__":

@@ -110,3 +110,33 @@ def test_data_parallel_step_matches_single_process_world2():
     for a, b, c in zip(m.parameters(), res[0], res[1]):
         assert (b == c).all()                                       # ranks stay bit-identical
         assert torch.allclose(a.detach(), torch.from_numpy(b), atol=1e-6)
+
+
+def _bench(*argv, env=None, timeout=600):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("workload,nbytes", [("layer", 4 * 596001), ("vit", 4 * 5397972)])
+def test_bench_self_launch_two_ranks_gloo(workload, nbytes):
+    """`python bench.py --gpus 2` as a plain command: bench.py starts the ranks itself (torch.distributed.run, 127.0.0.1), every rank
+    all-reduces ONE flat gradient bucket of the workload's real size per step, rank 0 prints one JSON line (CPU rehearsal: gloo)."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--workload", workload)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["config"]["parallelism"] == "dp2" and j["scaling"] == "weak"
+    assert j["config"]["grad_allreduce_bytes"] == nbytes and j["config"]["allreduce_ok"] is True
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    r = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)

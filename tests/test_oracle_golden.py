@@ -94,3 +94,19 @@ def test_sdpa(name):
     out, cache = sdpa.baseline_module_fwd(d["x"].astype(np.float64), p, meta["heads"], d.get("attn_mask"))
     dx, grads = sdpa.baseline_module_bwd(d["w"].astype(np.float64), cache)
     _check(out, dx, grads, d, gref)
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names("ew_") if "unshared" not in n])
+def test_torch_cpu_restatement_vs_reference_golden(name):
+    """oracle/edgewise_torch.py (the CPU baseline bench.py times: means-only formulation, autograd backward) == reference fixtures"""
+    import torch
+    from oracle import edgewise_torch as oet
+    d, params, gref, meta = load_golden(name)
+    p = {k: torch.from_numpy(np.ascontiguousarray(v)).double().requires_grad_(True) for k, v in params.items()}
+    x = torch.from_numpy(d["x"]).double().requires_grad_(True)
+    y = oet.edgewise_layer(x, p, meta["heads"], meta["n_views"], meta["beta_not"])
+    (y * torch.from_numpy(d["w"]).double()).sum().backward()
+    assert np.abs(y.detach().numpy() - d["y"]).max() <= 1e-4
+    assert np.abs(x.grad.numpy() - d["dx"]).max() <= 1e-4 * max(1.0, np.abs(d["dx"]).max())
+    for k, g in gref.items():
+        assert np.abs(p[k].grad.numpy() - g).max() <= 1e-4 * max(1.0, np.abs(g).max()), k

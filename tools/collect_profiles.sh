@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): bench + rocprofv3 kernel-trace stats + PMC passes (each its own run) for round $1
 set -o pipefail
-R=${1:-r01}
+R=${1:-r02}
 export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$R
@@ -17,6 +17,8 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INS
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_grbm.log 2>&1 || exit 1
 for p in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_grbm; do python3 tools/pmc_summary.py "$OUT/$p/*/*counter_collection.csv" > $OUT/$p.txt; done
 cp $OUT/kt/*/*kernel_stats.csv $OUT/kernel_stats.csv
+cp $OUT/kernel_stats.csv $ROOT/profiles/${R}_fused_kernel_stats.csv
+for p in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_grbm; do cp $OUT/$p.txt $ROOT/profiles/${R}_$p.txt; done
 python3 - "$OUT" <<'PY'
 import json, re, sys
 out = sys.argv[1]
@@ -27,7 +29,8 @@ def grab(path):
         if m and cur:
             res.setdefault(cur, {})[m.group(1)] = float(m.group(2))
         elif "mopk" in line:
-            m2 = re.search(r"(ew_fused_\w+_kernel)", line)
+            # keep the template arguments: the backward core is three launches of one kernel template (<.., 0|1|2>)
+            m2 = re.search(r"(ew_fused_\w+_kernel<[^>]*>)", line)
             cur = m2.group(1) if m2 else None
     return res
 f, w = grab(out + "/pmc_fetch.txt"), grab(out + "/pmc_write.txt")
@@ -42,4 +45,5 @@ PY
 # bench last: its roofline.traffic field reads the PMC-derived file produced above
 cp $OUT/hbm_traffic.json $ROOT/profiles/${R}_hbm_traffic.json
 python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err || exit 1
+tail -1 $OUT/bench.json > $ROOT/profiles/${R}_bench.json
 tail -1 $OUT/bench.json | cut -c1-600

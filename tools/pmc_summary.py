@@ -6,7 +6,7 @@ for f in glob.glob(pat):
     rows = list(csv.DictReader(open(f)))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in rows:
-        agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         if "mopk" not in k:
             continue
