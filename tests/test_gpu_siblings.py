@@ -382,6 +382,42 @@ def test_vit_mop_shapes_and_gate_api():
     assert gates.ndim == 4 and gates.shape[1] == 1 and views.shape[1] == 2 and kernels.shape[1] == 1
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", golden_names("vit_"))
+def test_vit_mop_vs_reference_golden(name, prec):
+    """ViT_MoP end to end against the reference (vit_mop.py:84-140): logits, the three gate maps, dx and every parameter gradient
+    (strided sample + L2 norm).  `vit_cfg0_5m` is BASELINE.json configs[0]: 5,397,972 parameters, d = 384, 6 heads, 5 views.
+    The parameters are regenerated from the fixture's seed (tests/vit_fixture.py) and loaded with strict=True."""
+    import mop_amd
+    from mop_amd.nn import ViT_MoP
+    from vit_fixture import fill_params, grad_sample
+    d, _, _, meta = load_golden(name)
+    shapes = {k[6:]: tuple(int(v) for v in d[k]) for k in d if k.startswith("shape:")}        # the reference's state_dict order
+    vals = fill_params(shapes, int(meta["param_seed"]))
+    m = ViT_MoP(dim=int(meta["dim"]), depth=int(meta["depth"]), heads=int(meta["heads"]), n_classes=int(meta["n_classes"]),
+                n_views=int(meta["n_views"]), n_kernels=int(meta["n_kernels"]), drop_path=0.0)
+    m.load_state_dict({k: torch.from_numpy(v).reshape(shapes[k]) for k, v in vals.items()}, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == int(meta["n_params"])
+    mop_amd.set_precision(prec)
+    m = m.cuda().eval()
+    x = torch.from_numpy(d["x"]).cuda().requires_grad_(True)
+    y = m(x)
+    y.backward(torch.from_numpy(d["w"]).cuda())
+    torch.cuda.synchronize()
+    tol, gtol = TOL[prec]
+    assert max_abs(y.detach().cpu().numpy(), d["y"]) <= tol, f"logits {max_abs(y.detach().cpu().numpy(), d['y']):.3e}"
+    gate, views, kernels = m.get_gate_maps(x.detach())
+    for got, key in ((gate, "gate"), (views, "views"), (kernels, "kernels")):
+        assert got.shape == d[key].shape and max_abs(got.cpu().numpy(), d[key]) <= tol * max(1.0, float(np.abs(d[key]).max())), key
+    assert rel_err(x.grad.cpu().numpy(), d["dx"]) <= gtol, f"dx {rel_err(x.grad.cpu().numpy(), d['dx']):.3e}"
+    gscale = max(float(d[k]) for k in d if k.startswith("gnorm:"))
+    for k, p in m.named_parameters():
+        smp, nrm = grad_sample(p.grad.detach().float().cpu().numpy())
+        ref_s, ref_n = d["gsample:" + k], float(d["gnorm:" + k])
+        assert abs(float(nrm) - ref_n) <= gtol * max(ref_n, 1e-3 * gscale), f"|grad {k}| {float(nrm):.4e} vs {ref_n:.4e}"
+        assert max_abs(smp, ref_s) <= gtol * max(float(np.abs(ref_s).max()), 1e-3 * gscale / max(1.0, np.sqrt(p.numel()))), f"grad sample {k}"
+
+
 # ---- BASELINE.json config sizes: size-independent properties of the fused sibling kernels (no oracle at these sizes)
 def test_sdpa_whisper_size_key_permutation_and_value_linearity():
     """T=3000, d=384, H=6 (config 5): non-causal attention is invariant to a joint permutation of keys/values and linear in v."""

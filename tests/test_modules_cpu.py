@@ -205,3 +205,16 @@ def test_token_linear_matches_nn_linear_forward_and_gradients():
     assert torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-4)
     assert torch.equal(lin(x2), ref(x2))                       # CPU tensors take the plain F.linear branch
+
+
+@pytest.mark.parametrize("name", golden_names("vit_"))
+def test_vit_mop_state_dict_matches_the_reference_layout(name):
+    """same keys, shapes and ORDER as the reference's ViT_MoP state_dict (recorded in the fixture); 5,397,972 parameters at configs[0]"""
+    from mop_amd.nn import ViT_MoP
+    d, _, _, meta = load_golden(name)
+    shapes = {k[6:]: tuple(int(v) for v in d[k]) for k in d if k.startswith("shape:")}
+    m = ViT_MoP(dim=int(meta["dim"]), depth=int(meta["depth"]), heads=int(meta["heads"]), n_classes=int(meta["n_classes"]),
+                n_views=int(meta["n_views"]), n_kernels=int(meta["n_kernels"]), drop_path=0.0)
+    ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert list(ours.items()) == list(shapes.items())
+    assert sum(p.numel() for p in m.parameters()) == int(meta["n_params"])

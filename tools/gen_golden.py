@@ -286,8 +286,41 @@ def sdpa_cases():
         _save(name, _run(mod, x, fk, extra, bf16_self=True))
 
 
+def vit_cases():
+    """ViT_MoP end to end (vit_mop.py:84-140; reference tests/test_forward_shapes.py:12-28): logits, gate maps, dx and sampled
+    parameter gradients.  Parameters come from tests/vit_fixture.py (numpy stream, not stored): BASELINE.json configs[0] is the
+    5,397,972-parameter model (dim 384, depth 3, heads 6, 5 views) on 32x32 images (N = 64 tokens)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from vit_fixture import fill_params, grad_sample
+    from mop.models.vit_mop import ViT_MoP
+    cases = [("vit_tiny_d64", dict(dim=64, depth=2, heads=4, n_classes=10, n_views=3, n_kernels=2, drop_path=0.0), 3, 900),
+             ("vit_cfg0_5m", dict(dim=384, depth=3, heads=6, n_classes=100, n_views=5, n_kernels=3, drop_path=0.0), 2, 901)]
+    for name, kw, B, seed in cases:
+        torch.manual_seed(seed)
+        mod = ViT_MoP(**kw).eval()
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        vals = fill_params(shapes, seed)
+        mod.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(shapes[k]) for k, v in vals.items()}, strict=True)
+        x = torch.randn(B, 3, 32, 32).requires_grad_(True)
+        y = mod(x)
+        g = torch.Generator().manual_seed(4242)
+        w = torch.randn(y.shape, generator=g)
+        (y * w).sum().backward()
+        gate, Vm, Km = mod.get_gate_maps(x.detach())
+        out = {"x": x.detach().numpy(), "y": y.detach().numpy(), "w": w.numpy(), "dx": x.grad.numpy(),
+               "gate": gate.numpy(), "views": Vm.numpy(), "kernels": Km.numpy()}
+        for k, p in mod.named_parameters():
+            smp, nrm = grad_sample(p.grad.numpy())
+            out["gsample:" + k], out["gnorm:" + k] = smp, nrm
+        for k, v in shapes.items():
+            out["shape:" + k] = np.asarray(v, dtype=np.int64)
+        meta = dict(kind="vit_mop", param_seed=seed, n_params=sum(p.numel() for p in mod.parameters()), **kw)
+        out.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
+        _save(name, out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    groups = dict(ew=edgewise_cases, ewx=edgewise_variant_cases, cv=crossview_cases, wh=whisper_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
+    groups = dict(vit=vit_cases, ew=edgewise_cases, ewx=edgewise_variant_cases, cv=crossview_cases, wh=whisper_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
     for name in (sys.argv[1:] or list(groups)):               # e.g. `gen_golden.py ewx` regenerates one group only
         groups[name]()
