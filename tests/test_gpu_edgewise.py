@@ -392,3 +392,69 @@ def test_reduce_parts_matches_a_host_side_sum():
     for x, e in zip(outs[0], exp):
         assert float((x.double() - e).abs().max()) <= 1e-4 * max(1.0, float(e.abs().max()))
     assert lib.mopk_edgewise_reduce_parts(None, 0, 0, 0, 0, None) == -2 or lib.mopk_edgewise_reduce_parts(None, 0, 0, 0, 0, None) < 0
+
+
+@pytest.mark.parametrize("variant", ["dense_k3", "lowrank_lens", "dense_k3_lens"])
+def test_variants_vs_oracle_at_full_sequence_length(variant):
+    """N = 197 (the config's token count), one head of dk = 64: dense gate head with the 3x3 mid convolution and the dilated S lens
+    bank (attention_variants.py:250-272, :312-318, :425-442, :523-533) on the generic path in exact fp32 arithmetic vs the float64 oracle.
+    (The reference fixtures for these variants stop at N = 33.)"""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd.nn import EdgewiseMSA
+    N, D, H, V = 197, 64, 1, 3
+    kw = dict(n_views=V, share_qkv=True)
+    dil = None
+    if variant == "dense_k3":
+        kw.update(gate_mode="dense", use_k3=True, gate_init="and")
+    elif variant == "lowrank_lens":
+        dil = (1, 2)
+        kw.update(gate_mode="lowrank", gate_rank=2, gate_init="mix5", use_lens_bank=True, lens_dilations=dil)
+    else:
+        dil = (2,)
+        kw.update(gate_mode="dense", use_k3=True, gate_init="or", use_lens_bank=True, lens_dilations=dil)
+    mop_amd.set_precision("fp32")
+    torch.manual_seed(197)
+    m = EdgewiseMSA(D, H, **kw)
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("_scale"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif n_.endswith("conv2.bias"):
+                p.copy_(0.5 * torch.randn_like(p))          # the -5 preset leaves every gate (and its gradient) ~0
+        m.chain_value_logit.fill_(-0.5)
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    x = torch.randn(1, N, D).numpy()
+    w = torch.randn(1, N, D).numpy()
+    out, cache = oe.module_fwd(x.astype(np.float64), params, H, V, True, 0.5, lens_dilations=dil)
+    dx_ref, g_ref = oe.module_bwd(w.astype(np.float64), cache)
+    y, dx, grads = run_fwd_bwd(m.cuda().eval(), x, w)
+    assert max_abs(y, out) <= 1e-4, f"y {max_abs(y, out):.3e}"
+    assert rel_err(dx, dx_ref) <= 1e-3, f"dx {rel_err(dx, dx_ref):.3e}"
+    check_grads(grads, g_ref, 1e-3, floor=1e-3)
+
+
+def test_fused_lowrank_batch_of_three_at_full_size_vs_oracle():
+    """B = 3 images at the north-star layer shape (N = 197, D = 384, 6 heads, 5 views, r = 4), fused bf16 kernels vs the float64 oracle:
+    the reference fixture at this shape is B = 1, so batch striding of every launch (saved records, hand-off regions, partials) is
+    only covered here."""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd import ops, _lib
+    B, N, D, H, V, r = 3, 197, 384, 6, 5, 4
+    mop_amd.set_precision("bf16")
+    m = _mk(D, H, V, r, seed=3197)
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N + B)
+    x = torch.randn(B, N, D, generator=g).numpy()
+    w = torch.randn(B, N, D, generator=g).numpy()
+    out, cache = oe.module_fwd(x.astype(np.float64), params, H, V, True, 0.5)
+    dx_ref, g_ref = oe.module_bwd(w.astype(np.float64), cache)
+    y, dx, grads = run_fwd_bwd(m.cuda().eval(), x, w)
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED and ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_FUSED
+    assert max_abs(y, out) <= TOL_BF16
+    # every image separately: a stride bug would hit some images and not others
+    for b in range(B):
+        assert rel_err(dx[b], dx_ref[b]) <= 3e-2, f"dx[{b}] {rel_err(dx[b], dx_ref[b]):.3e}"
+    noise = oracle_bf16_noise(oe.module_fwd, oe.module_bwd, x, w, params, H, V, True, 0.5, samples=2)
+    check_grads(grads, g_ref, GTOL_BF16, d=noise)
