@@ -16,6 +16,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmopk.so")
 PLAIN = ["api.hip", "edgewise_generic.hip", "attn_generic.hip", "sdpa_flash.hip", "quartet_flash.hip"]
 FUSED = ["edgewise_fused.hip", "edgewise_fused_bwd.hip"]
+FUSED_INST_ONLY = []      # files compiled per (NT, DK) only (entry points called from the files above)
 NTS, DKS = (1, 2, 4, 7), (16, 32, 64)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("MOPK_EXTRA_FLAGS"):  # compiler experiments, e.g. MOPK_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
@@ -39,12 +40,13 @@ def _hipcc() -> str:
 
 def _jobs():
     jobs = [(s, [], s.replace(".hip", ".o")) for s in PLAIN]
-    for s in FUSED:
+    for s in FUSED + FUSED_INST_ONLY:
         stem = s.replace(".hip", "")
         # fused bf16-MFMA kernels: relaxed fp (reassociation, contraction, approximate reciprocals) but inf/nan kept;
         # the exact-fp32 generic path is built without it
         fm = ["-ffast-math", "-fno-finite-math-only"]
-        jobs.append((s, ["-DMOPK_INST_NT=0", "-DMOPK_INST_DK=0"], f"{stem}_disp.o"))
+        if s not in FUSED_INST_ONLY:
+            jobs.append((s, ["-DMOPK_INST_NT=0", "-DMOPK_INST_DK=0"], f"{stem}_disp.o"))
         for nt in NTS:
             for dk in DKS:
                 jobs.append((s, fm + [f"-DMOPK_INST_NT={nt}", f"-DMOPK_INST_DK={dk}"], f"{stem}_nt{nt}_dk{dk}.o"))

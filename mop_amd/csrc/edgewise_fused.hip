@@ -263,6 +263,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, c); pack_tile(Xp[t][0], Xp[t][1], A); }
         }
         for (int m = 1; m < V; ++m) {
+            // this step's query fragments are requested BEFORE the export stores below: vmcnt retires in order (stores included), so
+            // a load issued behind the 14 export stores would wait for all of them (~16 k cycles per step at the HBM write rate)
+            const int v = forward ? m : V - 1 - m;
+            bf16x8 qe[KS];
+            make_qe2(qe, v);
             if (SAVE) {
                 // export the prefix product for the backward's dA GEMMs in "row slab" order: wave w' of the backward reads, per
                 // lane (key a = 32w' + r'), the fragments {T[i, a] : i} -> [wave w'][chunk q][lane], 16 B each.  That is the
@@ -290,10 +295,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 }
             }
             {
-                const int v = forward ? m : V - 1 - m;
                 FSTAMP2(forward && m == 1);
-                bf16x8 qe[KS];
-                make_qe2(qe, v);
                 const float c = view_const(qe, v);
                 FSTAMP2(forward && m == 1);
                 LDS_BARRIER();              // previous step's readers of AT are done

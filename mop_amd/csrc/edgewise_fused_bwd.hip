@@ -18,101 +18,9 @@
 // register tile, db via a 32x32 LDS transpose + MFMA) -> mean grads -> dC->, dC<- -> the two D-chains
 // (D_{m-1}^T = A_m D_m^T, row-block local) -> per view: dA_v (two GEMMs) -> softmax backward + direct +
 // mean terms -> dS_v -> dQe_v (K^T dS^T) and dK (dS^T Q through LDS) -> dq, dk, dsqk; dv from P^T dy, C->^T dy.
-#include "fused_common.h"
+#include "bwd_common.h"
 
 namespace mopk {
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-enum { PH_A = 0, PH_B = 1, PH_C = 2 };       // the three launches of the backward (see the header comment)
-
-struct BwdWs {
-    unsigned char *base;     // per-workgroup scratch (persistent workgroups: indexed by blockIdx)
-    size_t stride;           // bytes per workgroup
-    size_t oKT, oQT, oDYT, oV0s, oVLs, oDbp, oDW, oStamp;
-    unsigned char *xbase;    // per-(b,h) hand-off region between the three launches
-    size_t xstride;
-    size_t xSlots, xDmean;
-};
-// slab ids.  S_CF .. S_L live in the forward's `saved` record; X_* in the hand-off region
-enum { S_CF = 0, S_CB, S_SM, S_L, X_C3, X_DIR };   // X_DIR .. X_DIR+V-1 (direct score gradients per view), X_DR(V)+v: D_v of the -> chain, X_DL(V)+m: D'_m of the <- chain
-__host__ __device__ constexpr int X_DR(int V) { return X_DIR + V; }
-__host__ __device__ constexpr int X_DL(int V) { return X_DIR + 2 * V; }
-__host__ __device__ constexpr int X_COUNT(int V) { return 1 + 3 * V; }      // slabs in the hand-off region (ids X_C3 ..)
-
-template <int NT, int DK>
-struct BwdCfg {
-    using F = FusedCfg<NT, DK>;
-    static constexpr int NP = F::NP, LDA = F::LDA, DP = F::DP, DT = F::DT;
-    static constexpr size_t MAT = (size_t)NP * LDA * 2;
-    static constexpr size_t SLOT = (size_t)NT * 8 * 64 * 4;                // one packed slab of one wave
-    static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
-    // base: nwg per-workgroup scratch regions, then nbh hand-off regions
-    static BwdWs carve(void *base, int V, int nwg, int nbh) {
-        BwdWs w{};
-        size_t o = 0;
-        w.base = (unsigned char *)base;
-        w.oStamp = o; o += 512;                                    // diagnostic s_memtime stamps (MOPK_STAMPS builds): first, so tools find them at the workspace base
-        w.oKT = o; o += a256((size_t)DP * LDA * 2);
-        w.oQT = o; o += a256((size_t)DP * LDA * 2);
-        w.oDYT = o; o += a256((size_t)DP * LDA * 2);
-        w.oV0s = o; o += a256((size_t)NP * DK * 2);
-        w.oVLs = o; o += a256((size_t)NP * DK * 2);
-        w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
-        w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
-        w.stride = a256(o);
-        w.xbase = w.base + w.stride * (size_t)nwg;
-        size_t x = 0;
-        w.xSlots = x; x += a256((size_t)X_COUNT(V) * NT * SLOT);
-        w.xDmean = x; x += a256((size_t)(2 * V + 4) * NP * 4);
-        w.xstride = a256(x);
-        (void)nbh;
-        return w;
-    }
-    static size_t total_bytes(int V, int nwg, int nbh) {
-        const BwdWs w = carve(nullptr, V, nwg, nbh);
-        return w.stride * (size_t)nwg + w.xstride * (size_t)nbh;
-    }
-    // LDS: R region | Ksm | floats
-    static constexpr int GATE_BYTES = 4 * NP * BTS * 2 + 2 * 32 * LDA * 2 + NT * 32 * 40 * 2;   // bT | bmat | amat | tbuf
-    static constexpr int WSM_FLOATS = 2 * 16 * 19;                                                // gate-head weights + bias, row | col side
-    static constexpr int R_BYTES = imax(imax(NP * LDA * 2, 3 * DP * LDA * 2), GATE_BYTES + WSM_FLOATS * 4);
-    static constexpr int K_BYTES = F::K_BYTES;
-    static __host__ __device__ constexpr int small_floats(int V) {
-        // sqk[8][DK] qbar kbar vs0 vsL | rCr rCl cCr cCl | colpart[NT][NP] | rS cS [V][NP] (later: dmean[2V+4][NP]) | misc
-        return 16 * DK + 4 * DK + 4 * NP + NT * NP + imax(2 * V * NP, (2 * V + 4) * NP - NT * NP) + 2 * NT * DK + 16;
-    }
-    static __host__ __device__ constexpr int lds_bytes(int V) { return R_BYTES + K_BYTES + 4 * small_floats(V); }
-};
-
-__device__ __forceinline__ u32x4 as_u4(bf16x8 v) { return __builtin_bit_cast(u32x4, v); }
-__device__ __forceinline__ bf16x8 as_b8(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ void pack_tile_bf(bf16x8 &lo, bf16x8 &hi, const f32x16 &x) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { lo[j] = (short)f2bf(x[j]); hi[j] = (short)f2bf(x[8 + j]); }
-}
-__device__ __forceinline__ f32x16 unpack_tile_bf(bf16x8 lo, bf16x8 hi) {
-    f32x16 x;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { x[j] = bf2f((unsigned short)lo[j]); x[8 + j] = bf2f((unsigned short)hi[j]); }
-    return x;
-}
-__device__ __forceinline__ void pack_tile_h(u32x4 &lo, u32x4 &hi, const f32x16 &x) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) { lo[p] = pack_h2(x[2 * p], x[2 * p + 1]); hi[p] = pack_h2(x[8 + 2 * p], x[8 + 2 * p + 1]); }
-}
-__device__ __forceinline__ f32x16 unpack_tile_h(u32x4 lo, u32x4 hi) {
-    f32x16 x;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) { x[2 * p] = h2_lo(lo[p]); x[2 * p + 1] = h2_hi(lo[p]); x[8 + 2 * p] = h2_lo(hi[p]); x[8 + 2 * p + 1] = h2_hi(hi[p]); }
-    return x;
-}
-// cond ? x : 0 as a bit mask.  Written as a ternary, hipcc sinks the loads and arithmetic of x under the condition and emits
-// one exec-masked branch (with a full s_waitcnt) per element of a tile; the mask form stays straight-line code.
-__device__ __forceinline__ float keep_if(bool cond, float x) {
-    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned int, x) & (cond ? 0xffffffffu : 0u));
-}
-__device__ __forceinline__ f32x16 zero16() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
 
 template <int NT, int DK, typename IOT, int PH>
 __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W) {
@@ -216,16 +124,30 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         if (PH != PH_A) {                  // mean gradients of this (b,h) from PH_A
             for (int c = tl; c < (2 * V + 4) * NP; c += NTH) dmean[c] = xdmean[c];
         }
-        constexpr int CH = DK / 8;
-        for (int c = tl; c < NP * CH; c += NTH) {
-            const int j = c / CH, dc = c % CH;
-            bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, qv = kv, dv = kv, x0 = kv, xL = kv;
-            if (j < N) {
-                kv = load8_bf16<IOT>(kp + (int64_t)j * a.k.sn + dc * 8);
-                if (NEED_QT_LDS) qv = load8_bf16<IOT>(qp + (int64_t)j * a.q.sn + dc * 8);
-                if (NEED_DYT) dv = load8_bf16<IOT>(dp + (int64_t)j * a.dy.sn + dc * 8);
-                if (NEED_V0) x0 = load8_bf16<IOT>(v0p + (int64_t)j * a.v0.sn + dc * 8);
-                if (NEED_VL) xL = load8_bf16<IOT>(vLp + (int64_t)j * a.vL.sn + dc * 8);
+        constexpr int CH = DK / 8, ITER = (NP * CH + NTH - 1) / NTH;
+        // every thread requests all its chunks first (padded rows read row 0 and are zeroed afterwards): one exposed memory round trip
+        // for the whole staging pass instead of one per chunk
+        bf16x8 kvv[ITER], qvv[ITER], dvv[ITER], x0v[ITER], xLv[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = tl + it * NTH, j = c / CH, dc = c % CH, jc = (c < NP * CH && j < N) ? j : 0;
+            kvv[it] = load8_bf16<IOT>(kp + (int64_t)jc * a.k.sn + dc * 8);
+            qvv[it] = dvv[it] = x0v[it] = xLv[it] = kvv[it];
+            if (NEED_QT_LDS) qvv[it] = load8_bf16<IOT>(qp + (int64_t)jc * a.q.sn + dc * 8);
+            if (NEED_DYT) dvv[it] = load8_bf16<IOT>(dp + (int64_t)jc * a.dy.sn + dc * 8);
+            if (NEED_V0) x0v[it] = load8_bf16<IOT>(v0p + (int64_t)jc * a.v0.sn + dc * 8);
+            if (NEED_VL) xLv[it] = load8_bf16<IOT>(vLp + (int64_t)jc * a.vL.sn + dc * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = tl + it * NTH, j = c / CH, dc = c % CH;
+            if (c >= NP * CH) continue;
+            const bool ok = j < N;
+            bf16x8 kv, qv, dv, x0, xL;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                kv[e] = ok ? kvv[it][e] : (short)0; qv[e] = ok ? qvv[it][e] : (short)0; dv[e] = ok ? dvv[it][e] : (short)0;
+                x0[e] = ok ? x0v[it][e] : (short)0; xL[e] = ok ? xLv[it][e] : (short)0;
             }
             *(bf16x8 *)&Ksm[j * LDK + dc * 8] = kv;
             const int col = (j & ~15) + kperm16(j & 15);
@@ -244,9 +166,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 sL[e] = (short)f2bf(bf2f((unsigned short)xL[e]) * scL[e]);
             }
             if (NEED_V0) *(bf16x8 *)&V0s[j * DK + dc * 8] = s0;
-            if (NEED_VL) *(bf16x8 *)&VLs[j * DK + dc * 8] = sL;
+            if (NEED_VL) *(bf16x8 *)&R[j * LDK + dc * 8] = sL;        // PH_B: scaled vL rows in LDS ([NP][LDK] at the start of R, free until the first A image)
         }
-        if (DK < DP) for (int c = tl; c < (DP - DK) * LDA; c += NTH) { R[DK * LDA + c] = 0; R[(DP + DK) * LDA + c] = 0; R[(2 * DP + DK) * LDA + c] = 0; }
+        if (DK < DP && PH != PH_B)          // zero rows of the transposed images (PH_B builds none: its R holds the vL rows here)
+            for (int c = tl; c < (DP - DK) * LDA; c += NTH) { R[DK * LDA + c] = 0; R[(DP + DK) * LDA + c] = 0; R[(2 * DP + DK) * LDA + c] = 0; }
         __syncthreads();
         for (int c = tl; c < DP * LDA / 8; c += NTH) {
             if (NEED_KT) ((u32x4 *)KT)[c] = ((const u32x4 *)R)[c];
@@ -398,14 +321,41 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     };
     // Xn = Am . Xp for all output tiles, result re-packed (chain state never exists as an fp32 slab)
     auto gemm_packed = [&](bf16x8 (&Xp)[NT][2], const unsigned short *Am) {
+        // Xn[to] = Am[32 to + r][:] . Xp: the NT x 2NT A-fragment reads form ONE stream that runs PF fragments ahead of the MFMAs.
+        // Reads and their waits are inline asm (hipcc sinks each compiler-visible read next to its MFMA and waits lgkmcnt(0) behind
+        // it: read -> wait -> MFMA per k-step); asm statements keep their order and LDS returns in order, so before fragment f only
+        // the younger reads may be outstanding.
+        constexpr int NK = 2 * NT, NF = NT * NK, PF = 6;
         bf16x8 Xn[NT][2];
+        const unsigned abase = (unsigned)(uintptr_t)(Am + r * LDA + 8 * h);
+        unsigned rowb[NT];                                  // + 32 to rows (byte offsets exceed the 16-bit immediate)
 #pragma unroll
-        for (int to = 0; to + 1 < NT; to += 2) {
-            f32x16 a0 = zero16(), a1 = zero16();
-            gemm_tile2(a0, a1, Am, to, Xp);
-            pack_tile_bf(Xn[to][0], Xn[to][1], a0); pack_tile_bf(Xn[to + 1][0], Xn[to + 1][1], a1);
-        }
-        if (NT & 1) { const f32x16 acc = gemm_tile(zero16(), Am, NT - 1, Xp); pack_tile_bf(Xn[NT - 1][0], Xn[NT - 1][1], acc); }
+        for (int to = 0; to < NT; ++to) rowb[to] = abase + (unsigned)(32 * to * LDA * 2);
+        bf16x8 ring[PF];
+        static_for<0, (PF < NF ? PF : NF)>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            const unsigned rb = rowb[f / NK];
+            bf16x8 tmp;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(rb), "i"(32 * (f % NK)));
+            ring[f] = tmp;
+        });
+        f32x16 acc = zero16();
+        static_for<0, NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, to = f / NK, k = f % NK;
+            constexpr int pend = (NF - 1 - f) < (PF - 1) ? (NF - 1 - f) : (PF - 1);
+            if (k == 0) acc = zero16();
+            bf16x8 af = ring[f % PF];
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af) : "i"(pend));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[k >> 1][k & 1], acc, 0, 0, 0);
+            if constexpr (f + PF < NF) {
+                constexpr int fn = f + PF;
+                const unsigned rb = rowb[fn / NK];
+                bf16x8 tmp;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(rb), "i"(32 * (fn % NK)));
+                ring[fn % PF] = tmp;
+            }
+            if (k == NK - 1) pack_tile_bf(Xn[to][0], Xn[to][1], acc);
+        });
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
     };
@@ -523,14 +473,18 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         bf16x8 qe[KS];
         make_frag(qe, qrow, sqk2 + v * DK);
         const float c = cstats[v * NP + qi];
+        STAMP2();
         lds_barrier();                    // previous readers of dst are done
+        STAMP2();
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
             const f32x16 A = a_tile(qe, t, c);
             if (form_ii) store_ii_tile(dst, t, A);
             else { bf16x8 lo, hi; pack_tile_bf(lo, hi, A); store_i_tile(dst, t, lo, hi); }
         }
+        STAMP2();
         lds_barrier();
+        STAMP2();
     };
     STAMP();
     REFRESH();
@@ -985,7 +939,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             for (int t = 0; t < NT; ++t) {
                 const f32x16 cf = unpack_tile_bf(Cp[t][0], Cp[t][1]);
                 const f32x16 c3 = unpack_tile_bf(C3[t][0], C3[t][1]);
-                const f32x16 dyv = g_tile(VLs, dyf2, t);         // (dy vL^T)^T tile
+                f32x16 dyv = zero16();                           // (dy vL^T)^T tile: vL rows from LDS (staged over R by P0)
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 af = *(const bf16x8 *)&R[(32 * t + r) * LDK + 16 * s + 8 * h];
+                    dyv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dyf2[s], dyv, 0, 0, 0);
+                }
                 f32x16 d;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
@@ -996,10 +955,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
         }
         for (int v = V - 1; v >= 1; --v) {
+            STAMP2();
             slot_st(X_DR(V) + v, Dp);
             a_image(R, v, true);
             gemm_packed(Dp, R);                        // D_{v-1}^T = A_v D_v^T
         }
+        STAMP2();
         slot_st(X_DR(V), Dp);
     }
     }   // PH_B
@@ -1298,8 +1259,12 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
         hipLaunchKernelGGL(kfn, dim3(GRID_), block, lds, st, *a, W);                                              \
     } while (0)
-    if (a->io_dtype == MOPK_BF16) { MOPK_LAUNCH(unsigned short, PH_A, nwgA); MOPK_LAUNCH(unsigned short, PH_B, nwgB); MOPK_LAUNCH(unsigned short, PH_C, nwgA); }
-    else { MOPK_LAUNCH(float, PH_A, nwgA); MOPK_LAUNCH(float, PH_B, nwgB); MOPK_LAUNCH(float, PH_C, nwgA); }
+    if (a->io_dtype == MOPK_BF16) MOPK_LAUNCH(unsigned short, PH_A, nwgA); else MOPK_LAUNCH(float, PH_A, nwgA);
+    MOPK_CHECK_LAUNCH();
+    {   // launch B: the two D-chains
+        if (a->io_dtype == MOPK_BF16) MOPK_LAUNCH(unsigned short, PH_B, nwgB); else MOPK_LAUNCH(float, PH_B, nwgB);
+    }
+    if (a->io_dtype == MOPK_BF16) MOPK_LAUNCH(unsigned short, PH_C, nwgA); else MOPK_LAUNCH(float, PH_C, nwgA);
 #undef MOPK_LAUNCH
     MOPK_CHECK_LAUNCH();
     ew_fused_dw_reduce(a, W, nwgA, st);

@@ -1,10 +1,20 @@
 // Shared device helpers of the fused gfx950 Edgewise kernels (forward + backward).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace mopk {
 
 constexpr float EPSC = 1e-6f;   // attention_variants.py:516
+
+// compile-time loop: f(integral_constant<int, I>) for I in [B, E) -- the index is a constant expression inside the body (asm "i" operands)
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 constexpr int BTS = 24;         // bT row stride (ushorts): 16 k-slots + 8 pad (48 B, 16-B aligned)
 
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }

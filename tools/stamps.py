@@ -16,7 +16,7 @@ torch.cuda.synchronize()
 ws = ops.LAST_PATH["_bwd_ws"]
 st = struct.unpack("64Q", ws[:512].cpu().numpy().tobytes())
 names = {"A": ["P0 stage", "means", "P3 gates", "P4 mix state", "-", "P6 mix bwd", "P7 gate grads", "P8 dv", "end"],
-         "B": ["P0 stage", "chain", "end"],
+         "B": ["stage", "init D"] + [x for m in range(4) for x in ("export + q frags", "barrier", "A image", "barrier", "GEMM")] + ["last export", "item 2 ..."],
          "C": ["P0 stage", "GEMM1 (v=V-1)", "GEMM2", "rowdot", "dS pass", "dK", "rest of the views", "P11 out"]}[os.environ.get("MOPK_STAMP_PH", "C")]
 vals = [s for s in st if s]
 tot_c = vals[-1] - vals[0]
