@@ -320,13 +320,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
     };
     // Xn = Am . Xp for all output tiles, result re-packed (chain state never exists as an fp32 slab)
-    auto gemm_packed = [&](bf16x8 (&Xp)[NT][2], const unsigned short *Am) {
-        // Xn[to] = Am[32 to + r][:] . Xp: the NT x 2NT A-fragment reads form ONE stream that runs PF fragments ahead of the MFMAs.
-        // Reads and their waits are inline asm (hipcc sinks each compiler-visible read next to its MFMA and waits lgkmcnt(0) behind
-        // it: read -> wait -> MFMA per k-step); asm statements keep their order and LDS returns in order, so before fragment f only
-        // the younger reads may be outstanding.
+    // Out[to] (+)= Am[32 to + r][:] . Bf  with packed bf16 output tiles: the NT x 2NT A-fragment reads form ONE stream that runs PF
+    // fragments ahead of the MFMAs.  Reads and their waits are inline asm (hipcc sinks each compiler-visible read next to its MFMA
+    // and waits lgkmcnt(0) behind it: read -> wait -> MFMA per k-step); asm statements keep their order and LDS returns in order, so
+    // before fragment f only the younger reads may be outstanding.
+    auto gemm_stream = [&](bf16x8 (&Out)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
         constexpr int NK = 2 * NT, NF = NT * NK, PF = 6;
-        bf16x8 Xn[NT][2];
         const unsigned abase = (unsigned)(uintptr_t)(Am + r * LDA + 8 * h);
         unsigned rowb[NT];                                  // + 32 to rows (byte offsets exceed the 16-bit immediate)
 #pragma unroll
@@ -343,10 +342,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         static_for<0, NF>([&](auto fc) {
             constexpr int f = decltype(fc)::value, to = f / NK, k = f % NK;
             constexpr int pend = (NF - 1 - f) < (PF - 1) ? (NF - 1 - f) : (PF - 1);
-            if (k == 0) acc = zero16();
+            if (k == 0) acc = accumulate ? unpack_tile_bf(Out[to][0], Out[to][1]) : zero16();
             bf16x8 af = ring[f % PF];
             asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af) : "i"(pend));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[k >> 1][k & 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Bf[k >> 1][k & 1], acc, 0, 0, 0);
             if constexpr (f + PF < NF) {
                 constexpr int fn = f + PF;
                 const unsigned rb = rowb[fn / NK];
@@ -354,8 +353,12 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(rb), "i"(32 * (fn % NK)));
                 ring[fn % PF] = tmp;
             }
-            if (k == NK - 1) pack_tile_bf(Xn[to][0], Xn[to][1], acc);
+            if (k == NK - 1) pack_tile_bf(Out[to][0], Out[to][1], acc);
         });
+    };
+    auto gemm_packed = [&](bf16x8 (&Xp)[NT][2], const unsigned short *Am) {      // Xp <- Am . Xp
+        bf16x8 Xn[NT][2];
+        gemm_stream(Xn, Am, Xp, false);
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
     };
@@ -973,57 +976,58 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int dt = 0; dt < DT; ++dt) { dqa[dt] = zero16(); dka[dt] = zero16(); }
         for (int v = V - 1; v >= 0; --v) {
             REFRESH();
-            bf16x8 Dp[NT][2];
-            slot_ld(X_DR(V) + v, Dp);                  // D_v of the -> chain (PH_B)
-            // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index), kept as packed bf16 tiles; the
-            //      softmax-backward row dot  sum_j A_v dA_v  is taken from the fp32 accumulators of the LAST contribution
+            // a parked slab (X layout: lane = query, registers = keys) -> LDS image in AT format (rows = keys, k-permuted query columns).
+            // The transpose is taken on the matrix core: X . I comes back with lane = key, registers = queries, and its packed halves
+            // are 16-byte chunks of the image rows -- two ds_write_b128 per tile instead of sixteen 2-byte stores, and no slab array
+            // that a rolled store loop would demote to scratch memory.
+            auto stage_image = [&](int sid) {
+                const u32x4 *p = slot(sid);
+                bf16x8 idl, idh;              // B fragments of the 32 x 32 identity in the accumulator's k order
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    idl[e] = (short)(r == tile_row(e, h) ? 0x3f80 : 0);          // bf16(1.0)
+                    idh[e] = (short)(r == 16 + tile_row(e, h) ? 0x3f80 : 0);
+                }
+                u32x4 buf[NT][2];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { buf[t][0] = __builtin_nontemporal_load(&p[(2 * t) * 64]); buf[t][1] = __builtin_nontemporal_load(&p[(2 * t + 1) * 64]); }
+                lds_barrier();                     // previous readers of R are done
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(buf[t][0]), idl, zero16(), 0, 0, 0);
+                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(buf[t][1]), idh, tr, 0, 0, 0);
+                    bf16x8 lo, hi;
+                    pack_tile_bf(lo, hi, tr);     // exact: every entry is one bf16 value times 1.0
+                    // lane (r, h) now holds key 32t + r, queries 32w + {4h + 0..3, 8 + 4h + 0..3} (lo) and 16 + the same (hi):
+                    // chunks 4w + h and 4w + 2 + h of image row 32t + r
+                    unsigned short *dst = R + (32 * t + r) * LDA + 32 * w + 8 * h;
+                    *(bf16x8 *)dst = lo;
+                    *(bf16x8 *)(dst + 16) = hi;
+                }
+            };
+            // ---- dA_v^T slab (rows = keys, lanes = my queries as A_v's row index), kept as packed bf16 tiles
             bf16x8 dAp[NT][2];
             const int mp = V - 1 - v;
             if (v >= 1) {
                 bf16x8 Bf[NT][2];
-                load_rows(Bf, Tg + (size_t)(v - 1) * NP * LDA);          // in flight across the barriers below
+                stage_image(X_DR(V) + v);                                // D_v of the -> chain (PH_B)
+                load_rows(Bf, Tg + (size_t)(v - 1) * NP * LDA);          // in flight across the barrier
                 lds_barrier();
-                store_i_packed(R, Dp);
-                lds_barrier();
-#pragma unroll
-                for (int to = 0; to + 1 < NT; to += 2) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    f32x16 a0 = zero16(), a1 = zero16();
-                    gemm_tile2(a0, a1, R, to, Bf);
-                    pack_tile_bf(dAp[to][0], dAp[to][1], a0); pack_tile_bf(dAp[to + 1][0], dAp[to + 1][1], a1);
-                }
-                if (NT & 1) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const f32x16 acc = gemm_tile(zero16(), R, NT - 1, Bf);
-                    pack_tile_bf(dAp[NT - 1][0], dAp[NT - 1][1], acc);
-                }
+                gemm_stream(dAp, R, Bf, false);
             } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { dAp[t][0] = Dp[t][0]; dAp[t][1] = Dp[t][1]; }
+                slot_ld(X_DR(V), dAp);
             }
             {
-                bf16x8 Dl[NT][2];
-                __builtin_amdgcn_sched_barrier(0);   // keep these loads below GEMM 1 (register pressure)
-                slot_ld(X_DL(V) + mp, Dl);
+                __builtin_amdgcn_sched_barrier(0);
                 if (mp >= 1) {
                     bf16x8 Bf[NT][2];
+                    stage_image(X_DL(V) + mp);                           // D'_mp of the <- chain
                     load_rows(Bf, Ug + (size_t)(mp - 1) * NP * LDA);
                     lds_barrier();
-                    store_i_packed(R, Dl);
-                    lds_barrier();
-#pragma unroll
-                    for (int to = 0; to + 1 < NT; to += 2) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        f32x16 a0 = unpack_tile_bf(dAp[to][0], dAp[to][1]), a1 = unpack_tile_bf(dAp[to + 1][0], dAp[to + 1][1]);
-                        gemm_tile2(a0, a1, R, to, Bf);
-                        pack_tile_bf(dAp[to][0], dAp[to][1], a0); pack_tile_bf(dAp[to + 1][0], dAp[to + 1][1], a1);
-                    }
-                    if (NT & 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        const f32x16 acc = gemm_tile(unpack_tile_bf(dAp[NT - 1][0], dAp[NT - 1][1]), R, NT - 1, Bf);
-                        pack_tile_bf(dAp[NT - 1][0], dAp[NT - 1][1], acc);
-                    }
+                    gemm_stream(dAp, R, Bf, true);
                 } else {
+                    bf16x8 Dl[NT][2];
+                    slot_ld(X_DL(V), Dl);
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         f32x16 x = unpack_tile_bf(dAp[t][0], dAp[t][1]);
