@@ -1,6 +1,16 @@
 #!/bin/bash
-# Run on the GPU box (gpurun): bench + rocprofv3 kernel-trace stats + PMC passes (each its own run) for round $1
+# Run on the GPU box (gpurun): bench + rocprofv3 kernel-trace stats + PMC passes (each its own run) for round $1.
+# Only gpurun_out/ travels back from the box: afterwards run `bash tools/collect_profiles.sh --stage $1` in the dev container to copy
+# the summaries from gpurun_out/$1/ into profiles/ (the tracked directory).
 set -o pipefail
+if [ "$1" = "--stage" ]; then
+  R=${2:-r02}; S=gpurun_out/$R
+  cp $S/kernel_stats.csv profiles/${R}_fused_kernel_stats.csv
+  for p in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_grbm; do cp $S/$p.txt profiles/${R}_$p.txt; done
+  cp $S/hbm_traffic.json profiles/${R}_hbm_traffic.json
+  tail -1 $S/bench.json > profiles/${R}_bench.json
+  exit 0
+fi
 R=${1:-r02}
 export TMPDIR=/tmp
 ROOT=$PWD
