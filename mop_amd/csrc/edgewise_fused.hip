@@ -197,28 +197,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { lo[j] = (short)f2bf(x[j]); hi[j] = (short)f2bf(x[8 + j]); }
     };
-    auto store_AT_tile = [&](int t, bf16x8 lo, bf16x8 hi) {      // AT[key][perm(query)] for one tile
-#ifdef MOPK_WHATIF_NOSTORE     // timing experiment only (results are wrong)
-        if (a.B > 0) return;
-#endif
-        unsigned short *base = AT + (32 * t + 4 * h) * LDA + 32 * w + 16 * (r >> 4) + kperm16(r & 15);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            base[((g & 3) + 8 * (g >> 2)) * LDA] = (unsigned short)lo[g];
-            base[((g & 3) + 8 * (g >> 2) + 16) * LDA] = (unsigned short)hi[g];
-        }
-    };
-    auto gemm_tile = [&](int to, const bf16x8 (&Xp)[NT][2]) -> f32x16 {        // (A_m^T . X)[tile to]
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 af = *(const bf16x8 *)&(AT + r * LDA + 8 * h)[(32 * to) * LDA + 32 * t + 16 * s];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[t][s], acc, 0, 0, 0);
-            }
-        return acc;
-    };
     // epilogue of the LAST chain step for one output tile: v = log(C + eps); row-sum, per-wave column partials
     // (butterfly over the 32 lanes of a half: 16 shuffles per tile; lane r even ends with register r>>1)
     auto log_tile = [&](f32x16 &X, int t, float &rs) {
@@ -245,8 +223,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     };
     // chain product (transposed, row-block local):  X <- A_{o[V-1]}^T .. A_{o[1]}^T A_{o[0]}^T[:, I]
     // the last step hands every fp32 output tile to `epi(to, acc)`
+    const bool klast = N > NP - 16;        // N <= NP - 16: the last 16-wide k-step of every contraction over keys is all padding
     auto run_chain = [&](bool forward, auto &&epi) {
         bf16x8 Xp[NT][2];
+        bf16x8 idl, idh;
+        identity_frags(idl, idh, r, h);
         // the <- chain (run first) computes every view's softmax constant once and parks it in LDS for the -> chain
         auto view_const = [&](const bf16x8 (&qe)[KS], int v) -> float {
             if (forward) return cst[v * NP + qi];
@@ -277,12 +258,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 // (non-temporal stores: the record is not read again by this kernel; streaming it past L2 took 8 % off the forward)
                 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
                 u4 *out = (u4 *)(svb + (forward ? SL.oT : SL.oU) + (size_t)(m - 1) * NP * LDA * 2) + lane;
-                bf16x8 idl, idh;              // B fragments of the 32 x 32 identity in the accumulator's k order
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    idl[e] = (short)(r == tile_row(e, h) ? 0x3f80 : 0);          // bf16(1.0)
-                    idh[e] = (short)(r == 16 + tile_row(e, h) ? 0x3f80 : 0);
-                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     f32x16 tr = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -305,22 +280,31 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                     const f32x16 A = a_tile(qe, t, c);
                     bf16x8 lo, hi;
                     pack_tile(lo, hi, A);
-                    store_AT_tile(t, lo, hi);
+                    // AT[key][perm(query)]: the tile is transposed on the matrix core (lane = key, registers = this wave's 32 queries)
+                    // and leaves as two 16-byte LDS stores -- chunks 4w + h and 4w + 2 + h of image row 32t + r -- instead of sixteen
+                    // 2-byte ones
+                    f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, idl, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
+                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, idh, tr, 0, 0, 0);
+                    bf16x8 tl, th;
+                    pack_tile(tl, th, tr);
+                    unsigned short *dst = AT + (32 * t + r) * LDA + 32 * w + 8 * h;
+                    *(bf16x8 *)dst = tl;
+                    *(bf16x8 *)(dst + 16) = th;
                 }
                 FSTAMP2(forward && m == 1);
                 LDS_BARRIER();
                 FSTAMP2(forward && m == 1);
             }
+            auto zero_init = [](int) { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
             if (m < V - 1) {
                 bf16x8 Xn[NT][2];
-#pragma unroll
-                for (int to = 0; to < NT; ++to) { const f32x16 acc = gemm_tile(to, Xp); pack_tile(Xn[to][0], Xn[to][1], acc); }
+                gemm_stream_epi<NT>(AT + r * LDA + 8 * h, Xp, klast, zero_init,
+                                    [&](int to, const f32x16 &acc) { pack_tile(Xn[to][0], Xn[to][1], acc); });
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
                 FSTAMP2(forward && m == 1);
             } else {
-#pragma unroll
-                for (int to = 0; to < NT; ++to) { f32x16 acc = gemm_tile(to, Xp); epi(to, acc); }
+                gemm_stream_epi<NT>(AT + r * LDA + 8 * h, Xp, klast, zero_init, [&](int to, f32x16 acc) { epi(to, acc); });
             }
         }
     };
@@ -426,7 +410,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const bf16x8 af = *(const bf16x8 *)&(VTL + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xc[t][s], acc, 0, 0, 0);
+                    if (2 * t + s < 2 * NT - 1 || klast) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xc[t][s], acc, 0, 0, 0);
                 }
             if (qok) {
 #pragma unroll
@@ -632,7 +616,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bf16x8 af = *(const bf16x8 *)&(VT0 + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Pp[t][s], acc, 0, 0, 0);
+                if (2 * t + s < 2 * NT - 1 || klast) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Pp[t][s], acc, 0, 0, 0);
             }
         if (qok) {
 #pragma unroll

@@ -324,37 +324,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     // fragments ahead of the MFMAs.  Reads and their waits are inline asm (hipcc sinks each compiler-visible read next to its MFMA
     // and waits lgkmcnt(0) behind it: read -> wait -> MFMA per k-step); asm statements keep their order and LDS returns in order, so
     // before fragment f only the younger reads may be outstanding.
+    const bool klast = N > NP - 16;        // N <= NP - 16: the last 16-wide k-step of every contraction over tokens is all padding
     auto gemm_stream = [&](bf16x8 (&Out)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
-        constexpr int NK = 2 * NT, NF = NT * NK, PF = 6;
-        const unsigned abase = (unsigned)(uintptr_t)(Am + r * LDA + 8 * h);
-        unsigned rowb[NT];                                  // + 32 to rows (byte offsets exceed the 16-bit immediate)
-#pragma unroll
-        for (int to = 0; to < NT; ++to) rowb[to] = abase + (unsigned)(32 * to * LDA * 2);
-        bf16x8 ring[PF];
-        static_for<0, (PF < NF ? PF : NF)>([&](auto fc) {
-            constexpr int f = decltype(fc)::value;
-            const unsigned rb = rowb[f / NK];
-            bf16x8 tmp;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(rb), "i"(32 * (f % NK)));
-            ring[f] = tmp;
-        });
-        f32x16 acc = zero16();
-        static_for<0, NF>([&](auto fc) {
-            constexpr int f = decltype(fc)::value, to = f / NK, k = f % NK;
-            constexpr int pend = (NF - 1 - f) < (PF - 1) ? (NF - 1 - f) : (PF - 1);
-            if (k == 0) acc = accumulate ? unpack_tile_bf(Out[to][0], Out[to][1]) : zero16();
-            bf16x8 af = ring[f % PF];
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af) : "i"(pend));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Bf[k >> 1][k & 1], acc, 0, 0, 0);
-            if constexpr (f + PF < NF) {
-                constexpr int fn = f + PF;
-                const unsigned rb = rowb[fn / NK];
-                bf16x8 tmp;
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(rb), "i"(32 * (fn % NK)));
-                ring[fn % PF] = tmp;
-            }
-            if (k == NK - 1) pack_tile_bf(Out[to][0], Out[to][1], acc);
-        });
+        gemm_stream_epi<NT>(Am + r * LDA + 8 * h, Bf, klast,
+                            [&](int to) { return accumulate ? unpack_tile_bf(Out[to][0], Out[to][1]) : zero16(); },
+                            [&](int to, const f32x16 &acc) { pack_tile_bf(Out[to][0], Out[to][1], acc); });
     };
     auto gemm_packed = [&](bf16x8 (&Xp)[NT][2], const unsigned short *Am) {      // Xp <- Am . Xp
         bf16x8 Xn[NT][2];

@@ -1,6 +1,7 @@
 // Shared device helpers of the fused gfx950 Edgewise kernels (forward + backward).
 #pragma once
 #include <type_traits>
+#include <cstdint>
 
 #include "common.h"
 
@@ -174,4 +175,56 @@ template <int NT> __device__ __forceinline__ void tile_set(f32x16 (&X)[NT], int 
     }
 }
 
+
+// ---- stream GEMM over an LDS operand image -------------------------------------------------------------------------------------
+// For every output tile `to`:  acc = init(to);  acc += Am[32 to + r][:] . Bf;  epi(to, acc).   `am_lane` = Am + r * LDA + 8 * h.
+// The NT x 2NT A-fragment reads form ONE stream that runs PF fragments ahead of the MFMAs.  Reads and their waits are inline asm:
+// hipcc sinks each compiler-visible read next to its MFMA and waits lgkmcnt(0) behind it (read -> wait -> MFMA per k-step); asm
+// statements keep their order and LDS returns in order, so before fragment f only the younger reads may be outstanding.  LDS
+// traffic of `init` / `epi` only makes a counted wait conservative (it is younger than the reads that wait needs).
+// `klast` == false skips the last 16-wide k-step of every tile: with N <= NP - 16 that fragment is all padding (N = 197: the
+// contraction runs over 208 instead of 224).
+template <int NT, typename Init, typename Epi>
+__device__ __forceinline__ void gemm_stream_epi(const unsigned short *am_lane, const bf16x8 (&Bf)[NT][2], bool klast, Init &&init, Epi &&epi) {
+    constexpr int NP = NT * 32, LDA = NP + 8;
+    constexpr int NK = 2 * NT, NF = NT * NK, PF = 6;
+    const unsigned abase = (unsigned)(uintptr_t)am_lane;
+    unsigned rowb[NT];                                  // + 32 to rows (byte offsets exceed the 16-bit immediate)
+#pragma unroll
+    for (int to = 0; to < NT; ++to) rowb[to] = abase + (unsigned)(32 * to * LDA * 2);
+    bf16x8 ring[PF];
+    static_for<0, (PF < NF ? PF : NF)>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        const unsigned rb = rowb[f / NK];
+        bf16x8 tmp;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(rb), "i"(32 * (f % NK)));
+        ring[f] = tmp;
+    });
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static_for<0, NF>([&](auto fc) {
+        constexpr int f = decltype(fc)::value, to = f / NK, k = f % NK;
+        constexpr int pend = (NF - 1 - f) < (PF - 1) ? (NF - 1 - f) : (PF - 1);
+        if (k == 0) acc = init(to);
+        bf16x8 af = ring[f % PF];
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af) : "i"(pend));
+        if (k < NK - 1 || klast) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Bf[k >> 1][k & 1], acc, 0, 0, 0);
+        if constexpr (f + PF < NF) {
+            constexpr int fn = f + PF;
+            const unsigned rb = rowb[fn / NK];
+            bf16x8 tmp;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(rb), "i"(32 * (fn % NK)));
+            ring[fn % PF] = tmp;
+        }
+        if (k == NK - 1) epi(to, acc);
+    });
+}
+// B fragments of the 32 x 32 identity in the accumulator's k order: D = X . I returns a packed tile X (lane = row, registers = columns)
+// transposed (lane = column, registers = rows) -- two MFMAs per tile, exact (every entry is one bf16 value times 1.0)
+__device__ __forceinline__ void identity_frags(bf16x8 &idl, bf16x8 &idh, int r, int h) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        idl[e] = (short)(r == tile_row(e, h) ? 0x3f80 : 0);          // bf16(1.0)
+        idh[e] = (short)(r == 16 + tile_row(e, h) ? 0x3f80 : 0);
+    }
+}
 }  // namespace mopk
