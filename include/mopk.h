@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 111 /* 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
+#define MOPK_VERSION 112 /* 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -275,6 +275,35 @@ int mopk_crossview_bwd(const MopkCrossViewArgs *a, void *stream);
  * `chain_value_logit.grad` would otherwise need on the host side (attention_variants.py:374-378, :451 are the parameters).
  * Reads only B, V, H, dk and the four *_part pointers of `a`. */
 int mopk_edgewise_reduce_parts(const MopkEdgewiseArgs *a, float *dsqk, float *dvs0, float *dvsL, float *dlogit, void *stream);
+
+/* -------------------------------------------------------------------------- */
+/* LayerNorm prologue / residual epilogue of the attention path.
+ *
+ * Replaces, around the core, the `self.ln1(x)` of `x = x + self.dp1(self.attn(self.ln1(x)))`
+ * (experiments/cifar100_edgewise_gates.py:371-374; mop/models/components.py:96-98 is the same block): the forward applies
+ * torch.nn.LayerNorm (biased variance, eps inside the sqrt, fp32 statistics) to `rows` token rows of width `dim` and writes the
+ * result in `y_dtype` -- the dtype the qkv GEMM consumes -- in one pass; mean / rstd are kept for the backward.  The backward
+ * returns dx = dres + LN'(dy): `dres` is the gradient arriving on the residual branch (NULL: none), so the `x + ...` add of the
+ * block costs no extra pass.  dgamma / dbeta are summed over rows in a fixed order (bitwise reproducible).
+ * Rows are contiguous with leading dimensions x_ld / y_ld (elements, multiples of 8); dim % 8 == 0, dim <= 4096, pointers
+ * 16-byte aligned; anything else returns MOPK_ERR_UNSUPPORTED / MOPK_ERR_BAD_ARG. */
+typedef struct MopkLayerNormArgs {
+    int64_t rows;
+    int32_t dim;
+    int32_t x_dtype, y_dtype, p_dtype;   /* MopkDtype of x/dx/dres, of y/dy, of gamma/beta */
+    float eps;
+    int64_t x_ld, y_ld;
+    const void *x, *gamma, *beta;        /* beta may be NULL */
+    void *y;                             /* forward out */
+    float *mean, *rstd;                  /* (rows) fp32: forward out (both or neither), backward in */
+    const void *dy, *dres;               /* backward in; dres may be NULL */
+    void *dx;                            /* backward out (may alias dres) */
+    float *dgamma, *dbeta;               /* (dim) fp32 backward out; either may be NULL */
+    void *workspace;                     /* backward: mopk_layernorm_workspace_bytes() */
+} MopkLayerNormArgs;
+size_t mopk_layernorm_workspace_bytes(const MopkLayerNormArgs *a);
+int mopk_layernorm_fwd(const MopkLayerNormArgs *a, void *stream);
+int mopk_layernorm_bwd(const MopkLayerNormArgs *a, void *stream);
 
 /* -------------------------------------------------------------------------- */
 int mopk_version(void);

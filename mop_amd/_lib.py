@@ -108,6 +108,15 @@ class CrossViewArgs(C.Structure):
     ]
 
 
+class LayerNormArgs(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int64), ("dim", C.c_int32), ("x_dtype", C.c_int32), ("y_dtype", C.c_int32), ("p_dtype", C.c_int32),
+        ("eps", C.c_float), ("x_ld", C.c_int64), ("y_ld", C.c_int64),
+        ("x", _fp), ("gamma", _fp), ("beta", _fp), ("y", _fp), ("mean", _fp), ("rstd", _fp),
+        ("dy", _fp), ("dres", _fp), ("dx", _fp), ("dgamma", _fp), ("dbeta", _fp), ("workspace", _fp),
+    ]
+
+
 SYMBOLS = {
     "mopk_version": (C.c_int, []),
     "mopk_strerror": (C.c_char_p, [C.c_int]),
@@ -139,6 +148,9 @@ SYMBOLS = {
     "mopk_sdpa_fused_supported": (C.c_int, [C.POINTER(SdpaArgs)]),
     "mopk_sdpa_fwd": (C.c_int, [C.POINTER(SdpaArgs), C.c_void_p]),
     "mopk_sdpa_bwd": (C.c_int, [C.POINTER(SdpaArgs), C.c_void_p]),
+    "mopk_layernorm_workspace_bytes": (C.c_size_t, [C.POINTER(LayerNormArgs)]),
+    "mopk_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
+    "mopk_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
 }
 
 _lib = None

@@ -28,7 +28,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .linear import TokenLinear
+from .linear import TokenLinear, residual_linear
 
 # gate order inside the low-rank head: 0=and 1=or 2=not 3=chain   (:284)
 _LOWRANK_PRESET = {
@@ -194,7 +194,19 @@ class EdgewiseMSA(nn.Module):
             slots.append(torch.stack([q_l, k_l, qkv[:, :, 2]], dim=2))                   # (B,N,3,H,dk)
         return torch.stack(slots, dim=2)
 
-    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _project(self, y: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
+        """proj (+ proj_drop) of the core's output; with `residual` the block's `x + ...` add rides in the proj GEMM's epilogue"""
+        if residual is None:
+            return self.proj_drop(self.proj(y))
+        if y.is_cuda and y.dtype == residual.dtype == self.proj.weight.dtype and not torch.is_autocast_enabled() \
+                and not (self.training and self.proj_drop.p > 0):
+            return residual_linear(residual, y, self.proj.weight)
+        return residual + self.proj_drop(self.proj(y))
+
+    def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`residual` (not in the reference signature, default None = reference behaviour): returns `residual + attn(x)` with
+        the add fused into the output projection -- what `BlockEdgewise` wraps around this module (:371-374)."""
         self._check_supported(attn_mask)
         B, N, D = x.shape
         H, dk, V = self.h, self.dk, self.n_views
@@ -220,7 +232,7 @@ class EdgewiseMSA(nn.Module):
             y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,
                                           eh.col_proj.weight.squeeze(-1), eh.col_proj.bias,
                                           self.chain_value_logit, float(self.beta_not), n_s)
-            return self.proj_drop(self.proj(y))
+            return self._project(y, residual)
         # dense gate head and / or S lens bank: the library's generic path (MopkEdgewiseExt)
         lens_w = torch.stack([c.weight[:, 0] for c in self.lens_bank]) if self.use_lens_bank else None   # (L,S,3,3)
         var = ops.EdgewiseVariant(dense=dense, use_k3=dense and eh.use_k3,
@@ -233,7 +245,7 @@ class EdgewiseMSA(nn.Module):
             W3 = b3 = None
         y = ops.edgewise_general_core(qkv, sqk, vs0, vsL, self.chain_value_logit, head, float(self.beta_not), n_s, var,
                                       W3=W3, b3=b3, lens_w=lens_w)
-        return self.proj_drop(self.proj(y))
+        return self._project(y, residual)
 
 
 class BaselineMSA(nn.Module):

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .linear import TokenLinear
+from .linear import TokenLinear, residual_linear
 
 
 class DropPath(nn.Module):
@@ -68,8 +68,15 @@ class MLP(nn.Module):
         self.act = nn.GELU(approximate="tanh")
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x):
-        return self.drop(self.fc2(self.act(self.fc1(x))))
+    def forward(self, x, residual=None):
+        """`residual` (default None = reference behaviour): returns `residual + mlp(x)`, the add folded into fc2's GEMM"""
+        hid = self.act(self.fc1(x))
+        if residual is None:
+            return self.drop(self.fc2(hid))
+        if hid.is_cuda and hid.dtype == residual.dtype == self.fc2.weight.dtype and not torch.is_autocast_enabled() \
+                and not (self.training and self.drop.p > 0):
+            return residual_linear(residual, hid, self.fc2.weight)
+        return residual + self.drop(self.fc2(hid))
 
 
 class Block(nn.Module):

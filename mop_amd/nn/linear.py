@@ -28,6 +28,43 @@ def weight_grad_splits(rows: int, out_features: int) -> int:
     return s
 
 
+def _weight_grad(dy2: torch.Tensor, x2: torch.Tensor, n_out: int) -> torch.Tensor:
+    rows = x2.shape[0]
+    s = weight_grad_splits(rows, n_out)
+    if s > 1:
+        part = torch.bmm(dy2.reshape(s, rows // s, n_out).transpose(1, 2), x2.reshape(s, rows // s, x2.shape[1]))
+        return part.sum(0, dtype=torch.float32).to(dy2.dtype)
+    return dy2.t() @ x2
+
+
+class _ResidualLinearFn(torch.autograd.Function):
+    """``res + x @ W^T``: the residual add rides in the GEMM epilogue (hipBLASLt beta = 1), its gradient is the incoming one."""
+
+    @staticmethod
+    def forward(ctx, res, x, weight):
+        ctx.save_for_backward(x, weight)
+        n_out, n_in = weight.shape
+        return torch.addmm(res.reshape(-1, n_out), x.reshape(-1, n_in), weight.t()).view(res.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        n_out, n_in = weight.shape
+        dy2 = dy.reshape(-1, n_out)
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dx = (dy2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[2]:
+            dw = _weight_grad(dy2, x.reshape(-1, n_in), n_out).to(weight.dtype)
+        return (dy if ctx.needs_input_grad[0] else None), dx, dw
+
+
+def residual_linear(res: torch.Tensor, x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """``res + F.linear(x, weight)`` as one GEMM (reference: the `x + self.dp1(self.attn(...))` add of
+    experiments/cifar100_edgewise_gates.py:372 folded into `proj`, attention_variants.py:564)."""
+    return _ResidualLinearFn.apply(res, x, weight)
+
+
 class _TokenLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):

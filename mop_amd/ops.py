@@ -712,3 +712,71 @@ class _QuartetFn(torch.autograd.Function):
 def quartet_core(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights=False):
     return _QuartetFn.apply(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights,
                             _prec_for(q.dtype), _PATH)
+
+
+# ---- LayerNorm prologue / residual epilogue around the cores (mopk_layernorm_*) ----
+def layernorm_supported(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """shapes the HIP prologue covers (anything else: the caller keeps torch's LayerNorm)"""
+    d = x.shape[-1]
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and weight.dtype in (torch.float32, torch.bfloat16)
+            and d % 8 == 0 and d <= 4096 and x.numel() > 0)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype, with_residual):
+        _require_gpu(x, "layernorm")
+        xc = x.contiguous()
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        y = torch.empty(xc.shape, dtype=out_dtype, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        w = weight.detach().contiguous()
+        b = None if bias is None else bias.detach().to(w.dtype).contiguous()
+        a = L.LayerNormArgs(rows=rows, dim=d, x_dtype=_io_dtype(xc), y_dtype=_io_dtype(y), p_dtype=_io_dtype(w), eps=float(eps),
+                            x_ld=d, y_ld=d, x=_ptr(xc), gamma=_ptr(w), beta=_ptr(b), y=_ptr(y), mean=_ptr(mean), rstd=_ptr(rstd))
+        with _timed("layernorm_fwd"):
+            L.check(L.lib().mopk_layernorm_fwd(C.byref(a), _stream()), "mopk_layernorm_fwd")
+        ctx.save_for_backward(xc, w, mean, rstd)
+        ctx.meta = (float(eps), bias is not None, with_residual, weight.dtype, None if bias is None else bias.dtype)
+        if with_residual:
+            return xc.view_as(xc), y
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xc, w, mean, rstd = ctx.saved_tensors
+        eps, has_bias, with_residual, wdt, bdt = ctx.meta
+        dres, dy = (grads if with_residual else (None, grads[0]))
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        if dy is None:                                    # only the residual branch carries a gradient
+            return (dres, None, None, None, None, None)
+        dy = dy.contiguous()
+        if dres is not None:
+            dres = dres.to(xc.dtype).contiguous()
+        dx = torch.empty_like(xc)
+        dg = torch.empty(d, dtype=torch.float32, device=xc.device)
+        db = torch.empty(d, dtype=torch.float32, device=xc.device) if has_bias else None
+        a = L.LayerNormArgs(rows=rows, dim=d, x_dtype=_io_dtype(xc), y_dtype=_io_dtype(dy), p_dtype=_io_dtype(w), eps=eps,
+                            x_ld=d, y_ld=d, x=_ptr(xc), gamma=_ptr(w), mean=_ptr(mean), rstd=_ptr(rstd),
+                            dy=_ptr(dy), dres=_ptr(dres), dx=_ptr(dx), dgamma=_ptr(dg), dbeta=_ptr(db))
+        ws = torch.empty(max(1, L.lib().mopk_layernorm_workspace_bytes(C.byref(a))), dtype=torch.uint8, device=xc.device)
+        a.workspace = _ptr(ws)
+        with _timed("layernorm_bwd"):
+            L.check(L.lib().mopk_layernorm_bwd(C.byref(a), _stream()), "mopk_layernorm_bwd")
+        return dx, dg.to(wdt), (db.to(bdt) if has_bias else None), None, None, None
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-5,
+              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``F.layer_norm(x, (dim,), weight, bias, eps)`` written in ``out_dtype`` (default: x.dtype) by one HIP pass."""
+    return _LayerNormFn.apply(x, weight, bias, eps, out_dtype or x.dtype, False)
+
+
+def layernorm_residual(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float = 1e-5,
+                       out_dtype: Optional[torch.dtype] = None):
+    """(x_res, ln(x)) for a pre-norm residual branch ``x_res + f(ln(x))``: ``x_res`` is ``x`` itself, routed through the same
+    autograd node so that the backward returns ``d x_res + LN'(d ln)`` from ONE kernel instead of LN backward + an add."""
+    return _LayerNormFn.apply(x, weight, bias, eps, out_dtype or x.dtype, True)
