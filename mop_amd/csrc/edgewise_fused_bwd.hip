@@ -1012,16 +1012,23 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
             if (v == V - 1) STAMP();
             REFRESH();
-            // ---- softmax-backward row dot  sum_j A_v dA_v  (rolled pass over key tiles)
+            // ---- dA_v^T is parked in LDS for the two rolled passes below (indexed by a runtime tile number as a register array it
+            //      is demoted to private memory: 3 GB of scratch traffic per launch).  Tile t of wave w goes where the same wave
+            //      later writes tile t of the dS^T image -- rows 32t.., columns 32w.. of R, 2 KiB either way -- so the dS pass
+            //      replaces each tile in place and no other wave touches the slot before the barrier in front of the dK GEMM.
             const float cv = cstats[v * NP + qi];
             bf16x8 qe[KS];
             make_frag(qe, qrow, sqk2 + v * DK);           // base-2 scores: A = 2^(S' - c)
+            unsigned short *park = R + r * LDA + 32 * w + 16 * h;
+            lds_barrier();                                 // every wave is done reading the D image of the last GEMM
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { *(bf16x8 *)(park + 32 * t * LDA) = dAp[t][0]; *(bf16x8 *)(park + 32 * t * LDA + 8) = dAp[t][1]; }
+            // ---- softmax-backward row dot  sum_j A_v dA_v  (rolled pass over key tiles)
             float dot = 0.f;
 #pragma nounroll
             for (int t = 0; t < NT; ++t) {
                 const f32x16 A = a_tile(qe, t, cv);
-                bf16x8 dl_, dh_;
-                pk_get(dAp, t, dl_, dh_);
+                const bf16x8 dl_ = *(const bf16x8 *)(park + 32 * t * LDA), dh_ = *(const bf16x8 *)(park + 32 * t * LDA + 8);
                 const f32x16 dA = unpack_tile_bf(dl_, dh_);
 #pragma unroll
                 for (int g = 0; g < 16; ++g) dot = fmaf(A[g], dA[g], dot);
@@ -1042,18 +1049,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 bf16x8 nk[DT][2];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) { nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA]; nk[dt][1] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 16]; }
-                lds_barrier();                         // every wave is done reading the D images: R takes the dS^T image
 #pragma nounroll
                 for (int t = 0; t < NT; ++t) {
                     const u32x4 d0 = nd0, d1 = nd1;
                     bf16x8 kf[DT][2];
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) { kf[dt][0] = nk[dt][0]; kf[dt][1] = nk[dt][1]; }
-                    // this tile's dA fragments first: when the register allocator keeps the slab in scratch this is a reload, and
-                    // vmcnt is one in-order counter -- requested after the prefetch below, waiting for it would also wait for the prefetch
-                    bf16x8 dl_, dh_;
-                    pk_get(dAp, t, dl_, dh_);
-                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 dl_ = *(const bf16x8 *)(park + 32 * t * LDA), dh_ = *(const bf16x8 *)(park + 32 * t * LDA + 8);
                     {   // unconditional (the last iteration re-requests its own tile): a conditional prefetch makes the number of
                         // outstanding loads unknown at the join and every later s_waitcnt in the iteration becomes vmcnt(0)
                         const int tn = t + 1 < NT ? t + 1 : t;
