@@ -106,9 +106,12 @@ typedef struct MopkEdgewiseArgs {
     int32_t precision;  /* MopkPrecision                           */
     int32_t path;       /* MopkPath                                */
     int32_t save_for_backward; /* fused path: 1 = fwd also exports the chain state (prefix products, softmax constants,
-                                * log-means) and the mix state (mixed logits, view log-sum-exp, softmax row statistics,
-                                * P v0) into `saved`, and _bwd reads them instead of recomputing.  Must have the same value in
-                                * the fwd call, the bwd call and both *_bytes() queries.  0 = small `saved`, _bwd recomputes. */
+                                * log-means) and the mix state (mixed logits, view log-sum-exp in fp32, softmax row statistics,
+                                * P v0) into `saved`, and _bwd reads them.  0 = small `saved` (w * y_chain only); _bwd then
+                                * re-runs the forward kernel into its workspace first to obtain that record (workspace_bytes()
+                                * grows by the record's size).  Must have the same value in the fwd call, the bwd call and
+                                * both *_bytes() queries.  The fused _bwd is three launches on `stream` (mix backward, the two
+                                * D-chains, per-view gradients) that hand packed N x N slabs to each other through `workspace`. */
     float beta_not;     /* :361, used at :546 */
 
     MopkView5 q, k;          /* per-view (sv!=0) or shared (sv==0) queries / keys  :461-470 */
@@ -310,8 +313,9 @@ int mopk_version(void);
 const char *mopk_strerror(int status);
 /* 1 if the fused gfx950 kernels cover this Edgewise shape (N, dk, V, r). */
 int mopk_edgewise_fused_supported(const MopkEdgewiseArgs *a);
-/* name of the dominant kernel the last edgewise fwd/bwd on this thread launched
- * (static string; used by bench.py to match rocprofv3 kernel-trace rows). */
+/* name prefix of the dominant kernel(s) an edgewise fwd/bwd with these arguments launches (static string; bench.py matches
+ * rocprofv3 kernel-trace rows with it -- the fused backward is three launches of one template, `ew_fused_bwd_kernel<.., 0|1|2>`,
+ * and all three rows are summed). */
 const char *mopk_edgewise_dominant_kernel(const MopkEdgewiseArgs *a, int backward);
 
 #ifdef __cplusplus
