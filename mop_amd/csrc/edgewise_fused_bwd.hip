@@ -1296,6 +1296,14 @@ int ew_fused_bwd_lds_bytes(int nt, int dk, int V) {
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {
     if (!ew_fused_fwd_supported(a)) return 0;
     if (a->dq.sv != 0 || a->dk_.sv != 0) return 0;
+    // the backward reads dy and writes dq / dk / dv with 16-byte vectors, like the forward does q, k, v, y
+    const int64_t al = 16 / (a->io_dtype == MOPK_BF16 ? 2 : 4);
+    auto ok = [&](const void *p, int64_t sb, int64_t sh, int64_t sn) {
+        return p != nullptr && ((uintptr_t)p & 15) == 0 && sb % al == 0 && sh % al == 0 && sn % al == 0;
+    };
+    if (!ok(a->dy.ptr, a->dy.sb, a->dy.sh, a->dy.sn) || !ok(a->dq.ptr, a->dq.sb, a->dq.sh, a->dq.sn) ||
+        !ok(a->dk_.ptr, a->dk_.sb, a->dk_.sh, a->dk_.sn) || !ok(a->dv0.ptr, a->dv0.sb, a->dv0.sh, a->dv0.sn) ||
+        !ok(a->dvL.ptr, a->dvL.sb, a->dvL.sh, a->dvL.sn)) return 0;
     return 1;
 }
 size_t ew_fused_bwd_ws_bytes(const MopkEdgewiseArgs *a) {

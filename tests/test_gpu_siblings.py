@@ -430,6 +430,44 @@ def test_vit_mop_vs_reference_golden(name, prec):
         assert max_abs(smp, ref_s) <= gtol * max(float(np.abs(ref_s).max()), 1e-3 * gscale / max(1.0, np.sqrt(p.numel()))), f"grad sample {k}"
 
 
+def test_training_steps_match_the_reference_recipe():
+    """six steps of the reference's training recipe (AdamW + LinearLR -> cosine, experiments/cifar100_ab5_param_budgets.py:464-479,
+    loop :793-804) on ViT_MoP through `DataParallelStep`: loss and learning-rate sequences and the parameters after the last step
+    against the sequence recorded from the reference (tests/golden/train_vit_tiny_adamw6.npz)."""
+    import mop_amd
+    from mop_amd.nn import ViT_MoP
+    from mop_amd.training import DataParallelStep, make_optimizer_and_schedule
+    from vit_fixture import fill_params, grad_sample
+    d, _, _, meta = load_golden("train_vit_tiny_adamw6")
+    shapes = {k[6:]: tuple(int(v) for v in d[k]) for k in d if k.startswith("shape:")}
+    vals = fill_params(shapes, int(meta["param_seed"]))
+    m = ViT_MoP(dim=int(meta["dim"]), depth=int(meta["depth"]), heads=int(meta["heads"]), n_classes=int(meta["n_classes"]),
+                n_views=int(meta["n_views"]), n_kernels=int(meta["n_kernels"]), drop_path=0.0)
+    m.load_state_dict({k: torch.from_numpy(v).reshape(shapes[k]) for k, v in vals.items()}, strict=True)
+    mop_amd.set_precision("fp32")
+    m = m.cuda().train()
+    steps = int(meta["steps"])
+    opt, sched = make_optimizer_and_schedule(m, lr=float(meta["lr"]), weight_decay=float(meta["weight_decay"]), steps=steps,
+                                             warmup_frac=float(meta["warmup_frac"]))
+    step = DataParallelStep(m, opt, torch.nn.functional.cross_entropy, sched)
+    xs, ys = torch.from_numpy(d["x"]).cuda(), torch.from_numpy(d["labels"]).cuda()
+    losses, lrs = [], []
+    for i in range(steps):
+        lrs.append(opt.param_groups[0]["lr"])
+        losses.append(float(step(xs[i], ys[i])))
+    assert np.allclose(lrs, d["lr"], rtol=1e-12, atol=0.0)
+    assert np.allclose(losses, d["loss"], rtol=2e-4, atol=0.0), (losses, list(d["loss"]))
+    # parameters after the last step: Adam's update is lr * m / (sqrt(v) + eps), i.e. +-lr for a coordinate whose gradient is
+    # rounding noise, so single entries may differ by a few lr; norms and the bulk of the sample must agree
+    lr_sum = float(np.sum(d["lr"]))
+    for k, v in m.state_dict().items():
+        smp, nrm = grad_sample(v.detach().float().cpu().numpy())
+        ref_s, ref_n = d["psample:" + k], float(d["pnorm:" + k])
+        assert abs(float(nrm) - ref_n) <= 1e-3 * max(ref_n, 1e-3), k
+        diff = np.abs(smp - ref_s)
+        assert float(np.median(diff)) <= 1e-5 and float(diff.max()) <= 2.0 * lr_sum, (k, float(diff.max()))
+
+
 # ---- BASELINE.json config sizes: size-independent properties of the fused sibling kernels (no oracle at these sizes)
 def test_sdpa_whisper_size_key_permutation_and_value_linearity():
     """T=3000, d=384, H=6 (config 5): non-causal attention is invariant to a joint permutation of keys/values and linear in v."""

@@ -5,6 +5,8 @@ import math
 
 import numpy as np
 import pytest
+import os
+
 import torch
 
 from conftest import golden_names, load_golden
@@ -182,6 +184,29 @@ def test_vit_edgewise_state_dict_layout_and_checkpoint_roundtrip(tmp_path):
     ck = load_checkpoint(m2, None, path)
     assert ck["epoch"] == 3 and set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_training_recipe_matches_the_reference_fixture(tmp_path):
+    """learning-rate sequence of the reference recipe (experiments/cifar100_ab5_param_budgets.py:464-479) and the checkpoint
+    dictionary of mop/training/utils.py:120-144, as recorded from the reference in tests/golden/train_vit_tiny_adamw6.npz"""
+    import numpy as np
+    from conftest import GOLDEN
+    from mop_amd.training import make_optimizer_and_schedule, save_checkpoint
+    d = np.load(os.path.join(GOLDEN, "train_vit_tiny_adamw6.npz"))
+    m = torch.nn.Linear(4, 4)
+    opt, sched = make_optimizer_and_schedule(m, lr=float(d["meta:lr"]), weight_decay=float(d["meta:weight_decay"]),
+                                             steps=int(d["meta:steps"]), warmup_frac=float(d["meta:warmup_frac"]))
+    lrs = []
+    for _ in range(int(d["meta:steps"])):
+        lrs.append(opt.param_groups[0]["lr"])
+        m(torch.ones(1, 4)).sum().backward()
+        opt.step(); sched.step()
+    assert np.allclose(lrs, d["lr"], rtol=1e-12, atol=0.0), (lrs, d["lr"])
+    assert opt.defaults["weight_decay"] == float(d["meta:weight_decay"]) and type(opt).__name__ == "AdamW"
+    path = str(tmp_path / "c.pt")
+    save_checkpoint(m, opt, 3, 0.25, path)
+    ck = torch.load(path, map_location="cpu")
+    assert sorted(ck) == list(d["ckpt_keys"]) and sorted(ck["optimizer_state_dict"]) == list(d["ckpt_opt_keys"])
 
 
 def test_token_linear_matches_nn_linear_forward_and_gradients():

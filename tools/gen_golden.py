@@ -98,7 +98,8 @@ def _save(name, d):
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez(path, **d)
-    print(f"{name:40s} {os.path.getsize(path) / 1e6:7.3f} MB  |y|max={np.abs(d['y']).max():.4f}")
+    ymax = f"|y|max={np.abs(d['y']).max():.4f}" if "y" in d else ""
+    print(f"{name:40s} {os.path.getsize(path) / 1e6:7.3f} MB  {ymax}")
 
 
 def edgewise_cases():
@@ -319,8 +320,61 @@ def vit_cases():
         _save(name, out)
 
 
+def train_cases():
+    """k optimizer steps of the reference's training recipe on the reference's ViT_MoP: AdamW + LinearLR warm-up ->
+    CosineAnnealingLR exactly as experiments/cifar100_ab5_param_budgets.py:464-479 builds them, the step loop of :793-804
+    (zero_grad, cross-entropy, backward, opt.step, sched.step), and the checkpoint dictionary of mop/training/utils.py:120-144.
+    Recorded: per-step batches, losses, learning rates, a strided sample + norm of every parameter after the last step, the
+    checkpoint's keys."""
+    import tempfile
+    from torch import nn, optim
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from vit_fixture import fill_params, grad_sample
+    from mop.models.vit_mop import ViT_MoP
+    from mop.training.utils import save_checkpoint
+    kw = dict(dim=64, depth=2, heads=4, n_classes=10, n_views=3, n_kernels=2, drop_path=0.0)
+    steps, warmup_frac, lr, wd, B, seed = 6, 0.34, 3e-3, 5e-2, 4, 910
+    torch.manual_seed(seed)
+    mod = ViT_MoP(**kw).train()
+    shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    vals = fill_params(shapes, seed)
+    mod.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(shapes[k]) for k, v in vals.items()}, strict=True)
+    opt = optim.AdamW(mod.parameters(), lr=lr, weight_decay=wd)                                   # :465
+    warm = int(max(steps, 1) * max(warmup_frac, 0.0))                                             # :466
+    sched = optim.lr_scheduler.SequentialLR(                                                      # :468-476
+        opt, [optim.lr_scheduler.LinearLR(opt, start_factor=1e-3, total_iters=warm),
+              optim.lr_scheduler.CosineAnnealingLR(opt, T_max=max(steps - warm, 1))], milestones=[warm])
+    g = torch.Generator().manual_seed(seed + 1)
+    xs = torch.randn(steps, B, 3, 32, 32, generator=g)
+    ys = torch.randint(0, kw["n_classes"], (steps, B), generator=g)
+    losses, lrs = [], []
+    for i in range(steps):                                                                        # :793-804
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.zero_grad(set_to_none=True)
+        loss = nn.functional.cross_entropy(mod(xs[i]), ys[i])
+        loss.backward()
+        opt.step()
+        sched.step()
+        losses.append(float(loss))
+    out = {"x": xs.numpy(), "labels": ys.numpy(), "loss": np.asarray(losses, dtype=np.float64), "lr": np.asarray(lrs, dtype=np.float64)}
+    for k, v in mod.state_dict().items():
+        smp, nrm = grad_sample(v.detach().numpy())
+        out["psample:" + k], out["pnorm:" + k] = smp, nrm
+    for k, v in shapes.items():
+        out["shape:" + k] = np.asarray(v, dtype=np.int64)
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "c.pt")
+        save_checkpoint(mod, opt, 3, losses[-1], f)
+        ck = torch.load(f, map_location="cpu")
+    out["ckpt_keys"] = np.asarray(sorted(ck.keys()))
+    out["ckpt_opt_keys"] = np.asarray(sorted(ck["optimizer_state_dict"].keys()))
+    meta = dict(kind="train_vit_mop", param_seed=seed, steps=steps, warmup_frac=warmup_frac, lr=lr, weight_decay=wd, **kw)
+    out.update({"meta:" + k: np.asarray(v) for k, v in meta.items()})
+    _save("train_vit_tiny_adamw6", out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    groups = dict(vit=vit_cases, ew=edgewise_cases, ewx=edgewise_variant_cases, cv=crossview_cases, wh=whisper_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
+    groups = dict(train=train_cases, vit=vit_cases, ew=edgewise_cases, ewx=edgewise_variant_cases, cv=crossview_cases, wh=whisper_cases, mh=multihop_cases, qt=quartet_cases, sdpa=sdpa_cases)
     for name in (sys.argv[1:] or list(groups)):               # e.g. `gen_golden.py ewx` regenerates one group only
         groups[name]()
