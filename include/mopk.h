@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 112 /* 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
+#define MOPK_VERSION 113 /* 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -204,6 +204,8 @@ typedef struct MopkQuartetArgs {
     /* backward */
     MopkView4 dy, dq, dk_, dv, dq2, dk2;
     float *dmixture_part, *dqscale_part; /* (B,H) */
+    float dropout_p;         /* attn_dropout on the probabilities (quartet_attn_patch.py:119); see MopkSdpaArgs.dropout_p */
+    uint64_t dropout_seed;
 } MopkQuartetArgs;
 
 size_t mopk_quartet_saved_bytes(const MopkQuartetArgs *a);
@@ -231,6 +233,12 @@ typedef struct MopkSdpaArgs {
     MopkView4 y;
     void *saved, *workspace;
     MopkView4 dy, dq, dk_, dv;
+    /* attention dropout (`self.attn_drop(A)` components.py:62, attention_variants.py:45, `self.attn_dropout` quartet_attn_patch.py:119):
+     * probabilities are multiplied by keep(b,h,i,j) / (1 - dropout_p) after the softmax, keep = mopk_dropout_keep(); the same
+     * function is evaluated again in _bwd (nothing is stored), so pass the same p and seed to both.  0 = off.  Fused path only:
+     * the generic path returns MOPK_ERR_UNSUPPORTED when dropout_p > 0. */
+    float dropout_p;
+    uint64_t dropout_seed;
 } MopkSdpaArgs;
 
 size_t mopk_sdpa_saved_bytes(const MopkSdpaArgs *a);
@@ -239,6 +247,10 @@ int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream);
 int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream);  /* needs q,k,v, y (forward output), dy; mask/bias as in the forward */
 /* 1 if the fused (flash-style) gfx950 kernels take this call under MOPK_PATH_AUTO: bf16 arithmetic, dk 32/64, no mask/bias tensor */
 int mopk_sdpa_fused_supported(const MopkSdpaArgs *a);
+/* The dropout mask of the fused kernels as a host function (tests / reproducibility): 1 if edge (query i, key j) of head-batch
+ * index bh = b * H + h is kept under (seed, p).  Counter-based: lowbias32(lowbias32(i * 0x9E3779B1 + bh * 0x85EBCA77 + seed_hi)
+ * ^ seed_lo ^ j * 0xC2B2AE3D) >= p * 2^32. */
+int mopk_dropout_keep(uint64_t seed, float p, int64_t bh, int64_t i, int64_t j);
 
 /* --------------------------------------------------------------------------
  * CrossViewMixerMSA attention core.

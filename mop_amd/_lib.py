@@ -78,6 +78,7 @@ class QuartetArgs(C.Structure):
         ("y", View4), ("attn", _fp), ("saved", _fp), ("workspace", _fp),
         ("dy", View4), ("dq", View4), ("dk_", View4), ("dv", View4), ("dq2", View4), ("dk2", View4),
         ("dmixture_part", _fp), ("dqscale_part", _fp),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
     ]
 
 
@@ -90,6 +91,7 @@ class SdpaArgs(C.Structure):
         ("bias", _fp), ("bias_sb", C.c_int64), ("bias_sh", C.c_int64), ("bias_si", C.c_int64),
         ("y", View4), ("saved", _fp), ("workspace", _fp),
         ("dy", View4), ("dq", View4), ("dk_", View4), ("dv", View4),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
     ]
 
 
@@ -148,6 +150,7 @@ SYMBOLS = {
     "mopk_sdpa_fused_supported": (C.c_int, [C.POINTER(SdpaArgs)]),
     "mopk_sdpa_fwd": (C.c_int, [C.POINTER(SdpaArgs), C.c_void_p]),
     "mopk_sdpa_bwd": (C.c_int, [C.POINTER(SdpaArgs), C.c_void_p]),
+    "mopk_dropout_keep": (C.c_int, [C.c_uint64, C.c_float, C.c_int64, C.c_int64, C.c_int64]),
     "mopk_layernorm_workspace_bytes": (C.c_size_t, [C.POINTER(LayerNormArgs)]),
     "mopk_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
     "mopk_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),

@@ -1,5 +1,6 @@
 // extern "C" entry points of libmopk.so (see include/mopk.h).
 #include "common.h"
+#include "flash_common.h"
 
 namespace mopk {
 size_t ew_generic_saved_bytes(const MopkEdgewiseArgs *a);
@@ -63,6 +64,11 @@ using namespace mopk;
 extern "C" {
 
 int mopk_version(void) { return MOPK_VERSION; }
+int mopk_dropout_keep(uint64_t seed, float p, int64_t bh, int64_t i, int64_t j) {
+    const FaDrop d = fa_drop(p, seed);
+    if (!d.thresh) return 1;
+    return fa_drop_keep(d, fa_drop_row(d, (int)bh, (int)i), (int)j) ? 1 : 0;
+}
 
 const char *mopk_strerror(int s) {
     switch (s) {
@@ -145,8 +151,9 @@ int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
     if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
+    if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (sdpa_use_flash(a, false)) return sdpa_flash_fwd(a, (hipStream_t)stream);
-    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    if (a->path == MOPK_PATH_FUSED || a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;   // dropout lives in the fused kernels only
     return sdpa_fwd(a, (hipStream_t)stream);
 }
 int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream) {      // the fused path also reads `y` (the forward's output)
@@ -213,8 +220,9 @@ int mopk_quartet_fwd(const MopkQuartetArgs *a, void *stream) {
     int rc = base_ok(a->B, a->H, a->T, a->dh, a->io_dtype, a->precision); if (rc) return rc;
     if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
     if (a->use_quartet && (!v4ok(a->q2) || !v4ok(a->k2) || !a->mixture || !a->quartet_scale)) return MOPK_ERR_BAD_ARG;
+    if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (qt_use_flash(a)) return qt_flash_fwd(a, (hipStream_t)stream);
-    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
+    if (a->path == MOPK_PATH_FUSED || a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;   // dropout lives in the fused kernels only
     return qt_fwd(a, (hipStream_t)stream);
 }
 int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream) {    // the fused path also reads `y` (the forward's output)

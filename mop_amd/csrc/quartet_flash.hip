@@ -132,6 +132,8 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, c
     }
     const float4 st = qok ? ((const float4 *)stats)[(int64_t)bh * N + qi] : make_float4(0.f, 1.f, 0.f, 1.f);
     const QtNorm n1 = qt_norm(st.x, st.y, qs.eps1, N, 0.f, 0.f), n2 = qt_norm(st.z, st.w, qs.eps2, N, 0.f, 0.f);
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t rowh = fa_drop_row(drop, bh, qi);
     float m = FA_NEG, l = 0.f;
     f32x16 O[DT];
 #pragma unroll
@@ -179,6 +181,12 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, c
         ps += __shfl_xor(ps, 32, 64);
         l = fmaf(l, alpha, ps);
         m = mn;
+        if (drop.thresh) {                      // attn_dropout (:119): the row sum is of the undropped probabilities
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) S[hf][g] = fa_drop_keep(drop, rowh, k0 + 32 * hf + tile_row(g, h)) ? S[hf][g] * drop.inv_keep : 0.f;
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -240,6 +248,8 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a
     const float4 st = qok ? ((const float4 *)stats)[(int64_t)bh * N + qi] : make_float4(0.f, 1.f, 0.f, 1.f);
     const QtNorm n1 = qt_norm(st.x, st.y, qs.eps1, N, 0.f, 0.f), n2 = qt_norm(st.z, st.w, qs.eps2, N, 0.f, 0.f);
     const float Li = qok ? lse[(int64_t)bh * N + qi] : 0.f, di = qok ? delta[(int64_t)bh * N + qi] : 0.f;
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t rowh = fa_drop_row(drop, bh, qi);
     float A1 = 0.f, B1 = 0.f, A2 = 0.f, B2 = 0.f, gm = 0.f, gq = 0.f;
     const int nkt = min((N + FA_KT - 1) / FA_KT, (min(q0 + FA_QB, N) + FA_KT - 1) / FA_KT);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -261,7 +271,8 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a
                 if (qok && j < N && j <= qi) {
                     float z1, z2;
                     const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2) + qt_am<AM>(a, amp, qi, j);
-                    const float dsc = __builtin_amdgcn_exp2f(lg * FA_LOG2E - Li) * (dP[g] - di);
+                    const float dpd = drop.thresh ? (fa_drop_keep(drop, rowh, j) ? dP[g] * drop.inv_keep : 0.f) : dP[g];
+                    const float dsc = __builtin_amdgcn_exp2f(lg * FA_LOG2E - Li) * (dpd - di);
                     const float dz1 = DUAL ? dsc * ((1.f - qs.m) + qs.mq * z2) : dsc;
                     A1 += dz1; B1 = fmaf(dz1, S1[g] - n1.mu, B1);
                     if (DUAL) {
@@ -330,6 +341,8 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, co
     const float4 rw = qok ? ((const float4 *)rows)[(int64_t)bh * N + qi] : make_float4(0.f, 0.f, 0.f, 0.f);
     const QtNorm n1 = qt_norm(st.x, st.y, qs.eps1, N, rw.x, rw.y), n2 = qt_norm(st.z, st.w, qs.eps2, N, rw.z, rw.w);
     const float Li = qok ? lse[(int64_t)bh * N + qi] : 0.f, di = qok ? delta[(int64_t)bh * N + qi] : 0.f;
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t rowh = fa_drop_row(drop, bh, qi);
     f32x16 dQ[DT], dQ2[DUAL ? DT : 1];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dQ[dt] = fa_zero(); if (DUAL) dQ2[dt] = fa_zero(); }
@@ -354,7 +367,8 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, co
                 float z1, z2, dz1 = 0.f, dz2 = 0.f;
                 const float lg = qt_logit<DUAL>(S1[g], S2[g], n1, n2, qs, z1, z2) + qt_am<AM>(a, amp, qi, j);
                 if (j <= qi) {                                    // causal region: the soft-max sees this edge
-                    const float dsc = __builtin_amdgcn_exp2f(lg * FA_LOG2E - Li) * (dP[g] - di);
+                    const float dpd = drop.thresh ? (fa_drop_keep(drop, rowh, j) ? dP[g] * drop.inv_keep : 0.f) : dP[g];
+                    const float dsc = __builtin_amdgcn_exp2f(lg * FA_LOG2E - Li) * (dpd - di);
                     dz1 = DUAL ? dsc * ((1.f - qs.m) + qs.mq * z2) : dsc;
                     dz2 = dsc * qs.mq * z1;
                 }
@@ -382,6 +396,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, c
     __shared__ __attribute__((aligned(16))) unsigned short Qs[FA_KT * LDK], Gs[FA_KT * LDK], Qt[DK * FA_LDT], Gt[DK * FA_LDT];
     __shared__ __attribute__((aligned(16))) unsigned short Q2s[DUAL ? FA_KT * LDK : 8], Q2t[DUAL ? DK * FA_LDT : 8];
     __shared__ float4 Rs[FA_KT][3];                    // per query: (mu1, inv1, cc1, am1) (bs1, mu2, inv2, cc2) (am2, bs2, L, delta)
+    __shared__ uint32_t Hs[FA_KT];                     // dropout row hashes of the tile's queries
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int N = a.T;
     int kb, bh;
@@ -403,6 +418,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, c
     f32x16 dK[DT], dV[DT], dK2[DUAL ? DT : 1];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dK[dt] = fa_zero(); dV[dt] = fa_zero(); if (DUAL) dK2[dt] = fa_zero(); }
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
     const int nqt = (N + FA_KT - 1) / FA_KT;
     for (int qt = 0; qt < nqt; ++qt) {
         const int i0 = qt * FA_KT;
@@ -420,6 +436,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, c
             Rs[tid][0] = make_float4(n1.mu, n1.inv, n1.cc, n1.am);
             Rs[tid][1] = make_float4(n1.bs, n2.mu, n2.inv, n2.cc);
             Rs[tid][2] = make_float4(n2.am, n2.bs, L, dl);
+            Hs[tid] = fa_drop_row(drop, bh, i);
         }
         __syncthreads();
         const bool live = i0 + FA_KT > k0;               // causal: some query of this tile can see a key of this block
@@ -440,7 +457,10 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, c
                 const bool ok = kok && i < N;
                 if (ok && kj <= i) {
                     p = __builtin_amdgcn_exp2f(lg * FA_LOG2E - rc.z);
-                    const float dsc = p * (dP[g] - rc.w);
+                    float dpd = dP[g], pk = 1.f;
+                    if (drop.thresh) { pk = fa_drop_keep(drop, Hs[il], kj) ? drop.inv_keep : 0.f; dpd *= pk; }
+                    const float dsc = p * (dpd - rc.w);
+                    p *= pk;                                      // dV sees the dropped probabilities
                     dz1 = DUAL ? dsc * ((1.f - qs.m) + qs.mq * z2) : dsc;
                     dz2 = dsc * qs.mq * z1;
                 }

@@ -86,6 +86,8 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 2 : 3) sdpa_flash_fwd_kerne
         k2p = (const IOT *)u.k2.ptr + b * u.k2.sb + hh * u.k2.sh;
     }
     const FaMB mb = fa_mb(a, b, hh);
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t rowh = fa_drop_row(drop, bh, qi);
     float m = FA_NEG, l = 0.f;
     f32x16 O[DT];
 #pragma unroll
@@ -139,6 +141,12 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 2 : 3) sdpa_flash_fwd_kerne
         ps += __shfl_xor(ps, 32, 64);
         l = fmaf(l, alpha, ps);
         m = mn;
+        if (drop.thresh) {                      // the row sum above is of the undropped probabilities; P V sees keep / (1 - p)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) S[s2][g] = fa_drop_keep(drop, rowh, k0 + 32 * s2 + tile_row(g, h)) ? S[s2][g] * drop.inv_keep : 0.f;
+        }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -199,6 +207,8 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
     }
     const float Li = qok ? lse[(int64_t)bh * N + qi] : 0.f, di = qok ? delta[(int64_t)bh * N + qi] : 0.f;
     const FaMB mb = fa_mb(a, b, hh);
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t rowh = fa_drop_row(drop, bh, qi);
     f32x16 dQ[DT], dQ2[DUAL ? DT : 1];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dQ[dt] = fa_zero(); if (DUAL) dQ2[dt] = fa_zero(); }
@@ -234,7 +244,9 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
                 float z = DUAL ? fa_mix(S[g], T2[g], u.a2, u.g_or) : S[g];
                 if (MB) { bool blk; z = fa_apply_mb(z, mb, a, qi, j, blk); ok = ok && !blk; }
                 const float p = ok ? __builtin_amdgcn_exp2f(z - Li) : 0.f;
-                const float dz = p * (dP[g] - di) * sc;          // d logits / sqrt(dk)
+                float dp = dP[g];                                // dropout: dP = (dy v^T) keep / (1 - p); delta = dy . y already has it
+                if (drop.thresh) dp = fa_drop_keep(drop, rowh, j) ? dp * drop.inv_keep : 0.f;
+                const float dz = p * (dp - di) * sc;             // d logits / sqrt(dk)
                 if (DUAL) { float c1, c2; fa_mix_grad(S[g], T2[g], u.a2, u.g_or, c1, c2); dS[g] = dz * c1; dS2[g] = dz * c2; }
                 else dS[g] = dz;
             }
@@ -257,6 +269,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
     __shared__ __attribute__((aligned(16))) unsigned short Qs[FA_KT * LDK], Gs[FA_KT * LDK], Qt[DK * FA_LDT], Gt[DK * FA_LDT];
     __shared__ __attribute__((aligned(16))) unsigned short Q2s[DUAL ? FA_KT * LDK : 8], Q2t[DUAL ? DK * FA_LDT : 8];
     __shared__ float Ls[FA_KT], Ds[FA_KT];
+    __shared__ uint32_t Hs[FA_KT];                 // dropout row hashes of the tile's queries
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int N = a.N;
     int kb, bh;
@@ -279,6 +292,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) { dK[dt] = fa_zero(); dV[dt] = fa_zero(); if (DUAL) dK2[dt] = fa_zero(); }
     const FaMB mb = fa_mb(a, b, hh);
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
     const int nqt = (N + FA_KT - 1) / FA_KT, qt0 = CAUSAL ? k0 / FA_KT : 0;   // causal: queries before this key block see none of its keys
     FaTile<DK> fq, fg, fq2;               // q is pre-scaled exactly as the forward's fragments
     fa_fetch<DK, IOT>(fq, qp, a.q.sn, qt0 * FA_KT, N, c, tid);
@@ -299,6 +313,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
             const bool ok = i0 + tid < N;
             Ls[tid] = ok ? lse[(int64_t)bh * N + i0 + tid] : 0.f;
             Ds[tid] = ok ? delta[(int64_t)bh * N + i0 + tid] : 0.f;
+            Hs[tid] = fa_drop_row(drop, bh, i0 + tid);
         }
         __syncthreads();
 #pragma unroll
@@ -315,8 +330,10 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs
                 float z = DUAL ? fa_mix(S[g], T2[g], u.a2, u.g_or) : S[g];
                 if (MB) { bool blk; z = fa_apply_mb(z, mb, a, i, kj, blk); ok = ok && !blk; }
                 const float p = ok ? __builtin_amdgcn_exp2f(z - Ls[il]) : 0.f;
-                P[g] = p;
-                const float dz = p * (dP[g] - Ds[il]) * FA_LN2;   // Q' = q log2(e)/sqrt(dk)  ->  dK = (dS ln2)^T Q'
+                float dp = dP[g], pd = p;                         // dropout: dV sees P keep / (1 - p), dP = (dy v^T) keep / (1 - p)
+                if (drop.thresh) { const float kp = fa_drop_keep(drop, Hs[il], kj) ? drop.inv_keep : 0.f; dp *= kp; pd *= kp; }
+                P[g] = pd;
+                const float dz = p * (dp - Ds[il]) * FA_LN2;      // Q' = q log2(e)/sqrt(dk)  ->  dK = (dS ln2)^T Q'
                 if (DUAL) { float c1, c2; fa_mix_grad(S[g], T2[g], u.a2, u.g_or, c1, c2); dS[g] = dz * c1; dS2[g] = dz * c2; }
                 else dS[g] = dz;
             }

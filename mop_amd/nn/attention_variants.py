@@ -259,12 +259,11 @@ class BaselineMSA(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.training and self.attn_drop.p > 0:       # reference :45 applies dropout to the attention weights
-            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+        pdrop = float(self.attn_drop.p) if self.training else 0.0      # reference :45: dropout on the attention weights, inside the kernels
         B, N, D = x.shape
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
         causal = _is_causal_mask(attn_mask, N)      # tril mask -> in-kernel causal flag (keeps the call on the fused kernels)
-        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], None if causal else attn_mask, causal=causal)
+        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], None if causal else attn_mask, causal=causal, dropout_p=pdrop)
         return self.proj_drop(self.proj(y))
 
 

@@ -52,10 +52,9 @@ class MSA(nn.Module):
 
     def forward(self, x):
         B, N, D = x.shape
-        if self.training and self.attn_drop.p > 0:
-            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+        pdrop = float(self.attn_drop.p) if self.training else 0.0      # self.attn_drop(A) (:62), inside the kernels
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
-        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2])
+        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p=pdrop)
         return self.proj_drop(self.proj(y))
 
 

@@ -62,8 +62,7 @@ class CausalSelfAttention(nn.Module):
     def forward(self, x: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, need_weights: bool = False):
         B, T, C = x.shape
         H, Dh = self.n_head, self.head_dim
-        if self.training and self.attn_drop.p > 0:
-            raise NotImplementedError("attention dropout in training mode is not supported by the kernels yet")
+        pdrop = float(self.attn_drop.p) if self.training else 0.0      # attn_dropout on the probabilities (:119), inside the kernels
         if T > self.config.block_size:
             raise ValueError("Sequence length > block size")
         q = self.q_proj(x).view(B, T, H, Dh)
@@ -73,7 +72,7 @@ class CausalSelfAttention(nn.Module):
         q2 = self.q2_proj(x).view(B, T, H, Dh) if uq else None
         k2 = self.k2_proj(x).view(B, T, H, Dh) if uq else None
         out = ops.quartet_core(q, k, v, q2, k2, self.mixture, self.quartet_scale, attention_mask,
-                               self.config.score_norm_eps, uq, need_weights)
+                               self.config.score_norm_eps, uq, need_weights, dropout_p=pdrop)
         y, attn = out if need_weights else (out, None)
         y = self.resid_drop(self.o_proj(y))
         return (y, attn) if need_weights else y

@@ -99,12 +99,11 @@ class MultiheadSelfAttention(nn.Module):
         self.resid_drop = nn.Dropout(dropout)
 
     def forward(self, x: torch.Tensor, attn_bias: Optional[torch.Tensor] = None):
-        if self.training and self.attn_drop.p > 0:
-            raise NotImplementedError("attention dropout in training mode is not supported by the kernels yet")
+        pdrop = float(self.attn_drop.p) if self.training else 0.0      # dropout on the probabilities (:172), inside the kernels
         B, T, D = x.shape
         H, Dh = self.n_head, self.head_dim
         q, k, v = (p(x).view(B, T, H, Dh) for p in (self.q_proj, self.k_proj, self.v_proj))
-        y = ops.sdpa_core(q, k, v, bias=attn_bias, causal=self.causal)
+        y = ops.sdpa_core(q, k, v, bias=attn_bias, causal=self.causal, dropout_p=pdrop)
         return self.resid_drop(self.o_proj(y))
 
 

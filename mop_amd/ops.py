@@ -415,7 +415,7 @@ def _bias_f32(bias, B, H, N, dev):
 
 class _SdpaFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, mask, bias, causal, prec, path):
+    def forward(ctx, q, k, v, mask, bias, causal, prec, path, drop=(0.0, 0)):
         _require_gpu(q, "SDPA")
         lib = L.lib()
         q, k, v = _heads_view(q), _heads_view(k), _heads_view(v)
@@ -429,11 +429,15 @@ class _SdpaFn(torch.autograd.Function):
         bf, bs = _bias_f32(bias, B, H, N, dev)
         a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
         a.bias, (a.bias_sb, a.bias_sh, a.bias_si) = _ptr(bf), bs
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         y = torch.empty(B, N, H, dk, dtype=q.dtype, device=dev)
         a.y = _v4(y)
         if path == L.PATH_AUTO:       # resolve once so forward, backward and the size queries agree
             path = L.PATH_FUSED if lib.mopk_sdpa_fused_supported(C.byref(a)) else L.PATH_GENERIC
             a.path = path
+        if drop[0] > 0 and path != L.PATH_FUSED:
+            raise NotImplementedError("attention dropout runs in the fused bf16 kernels only (dk 32/64, bf16 arithmetic): "
+                                      "use bf16 tensors / set_precision('bf16'), or attn_drop = 0")
         LAST_PATH["sdpa_fwd"] = path
         saved = _bytes(lib.mopk_sdpa_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_sdpa_workspace_bytes(C.byref(a)), dev)
@@ -442,18 +446,19 @@ class _SdpaFn(torch.autograd.Function):
             rc = lib.mopk_sdpa_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_sdpa_fwd")
         ctx.save_for_backward(q, k, v, y, saved)
-        ctx.meta = (causal, prec, path, m8, ms, bf, bs)
+        ctx.meta = (causal, prec, path, m8, ms, bf, bs, drop)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
         q, k, v, y, saved = ctx.saved_tensors
-        causal, prec, path, m8, ms, bf, bs = ctx.meta
+        causal, prec, path, m8, ms, bf, bs, drop = ctx.meta
         B, N, H, dk = q.shape
         dev = q.device
         dy = dy.contiguous().to(q.dtype).view(B, N, H, dk)
         a = L.SdpaArgs()
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         a.B, a.H, a.N, a.dk = B, H, N, dk
         a.io_dtype, a.precision, a.path, a.causal = _io_dtype(q), prec, path, int(bool(causal))
         a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(y), _v4(dy)
@@ -467,12 +472,41 @@ class _SdpaFn(torch.autograd.Function):
         with _timed("sdpa_bwd"):
             rc = lib.mopk_sdpa_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_sdpa_bwd")
-        return dq, dk_, dv, None, None, None, None, None
+        return dq, dk_, dv, None, None, None, None, None, None
 
 
-def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False):
-    """q,k,v: (B,N,H,dk) views. Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive."""
-    return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype), _PATH)
+def dropout_seed() -> int:
+    """a fresh 63-bit seed for the in-kernel dropout mask, drawn from torch's CPU generator (so `torch.manual_seed` makes runs
+    reproducible, like it does for `nn.Dropout`)"""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def dropout_keep_mask(seed: int, p: float, B: int, H: int, N: int) -> torch.Tensor:
+    """the kernels' keep mask as a (B,H,N,N) bool tensor (host restatement of `mopk_dropout_keep`, vectorised; tests / debugging)"""
+    import numpy as np
+    def h32(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & np.uint64(0xffffffff)
+        x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & np.uint64(0xffffffff)
+        x ^= x >> np.uint64(16)
+        return x
+    M = np.uint64(0xffffffff)
+    lo, hi = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
+    t = float(p) * 4294967296.0
+    thresh = np.uint64(0xffffffff if t >= 4294967295.0 else (1 if t < 1.0 else int(t)))
+    bh = np.arange(B * H, dtype=np.uint64)[:, None, None]
+    i = np.arange(N, dtype=np.uint64)[None, :, None]
+    j = np.arange(N, dtype=np.uint64)[None, None, :]
+    row = h32((i * np.uint64(0x9E3779B1) + bh * np.uint64(0x85EBCA77) + hi) & M) ^ lo
+    keep = h32((row ^ ((j * np.uint64(0xC2B2AE3D)) & M)) & M) >= thresh
+    return torch.from_numpy(keep.reshape(B, H, N, N)) if p > 0 else torch.ones(B, H, N, N, dtype=torch.bool)
+
+
+def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
+    """q,k,v: (B,N,H,dk) views. Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive.  dropout_p > 0: the probabilities
+    are multiplied by keep / (1 - p) inside the fused kernels (mask = `dropout_keep_mask(seed, ...)`, seed drawn when None)."""
+    drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
+    return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype), _PATH, drop)
 
 
 _ANCHOR_MODES = {"fixed": 0, "argmax_row_sum": 1}          # any other string -> row 0 (reference :141-145)
@@ -631,7 +665,7 @@ def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_cha
 
 class _QuartetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, q2, k2, mixture, qscale, add_mask, eps, use_quartet, need_weights, prec, path):
+    def forward(ctx, q, k, v, q2, k2, mixture, qscale, add_mask, eps, use_quartet, need_weights, prec, path, drop=(0.0, 0)):
         _require_gpu(q, "CausalSelfAttention")
         lib = L.lib()
         ts = [_heads_view(t) for t in ((q, k, v, q2, k2) if use_quartet else (q, k, v))]
@@ -653,9 +687,13 @@ class _QuartetFn(torch.autograd.Function):
         a.y = _v4(y)
         attn = torch.empty(B, H, T, T, dtype=torch.float32, device=dev) if need_weights else None
         a.attn = _ptr(attn)
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         if path == L.PATH_AUTO:
             path = L.PATH_FUSED if lib.mopk_quartet_fused_supported(C.byref(a)) else L.PATH_GENERIC
             a.path = path
+        if drop[0] > 0 and path != L.PATH_FUSED:
+            raise NotImplementedError("attention dropout runs in the fused bf16 Quartet kernels only (head dim 32/64, bf16 arithmetic, "
+                                      "need_weights=False): use bf16 tensors / set_precision('bf16'), or dropout = 0")
         LAST_PATH["quartet_fwd"] = path
         saved = _bytes(lib.mopk_quartet_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_quartet_workspace_bytes(C.byref(a)), dev)
@@ -664,7 +702,7 @@ class _QuartetFn(torch.autograd.Function):
             rc = lib.mopk_quartet_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_quartet_fwd")
         ctx.save_for_backward(*ts, *sc, y, saved)
-        ctx.meta = (eps, use_quartet, prec, path, am, ams)
+        ctx.meta = (eps, use_quartet, prec, path, am, ams, drop)
         out = y.view(B, T, H * dh)
         if need_weights:
             ctx.mark_non_differentiable(attn)
@@ -674,7 +712,7 @@ class _QuartetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         lib = L.lib()
-        eps, use_quartet, prec, path, am, ams = ctx.meta
+        eps, use_quartet, prec, path, am, ams, drop = ctx.meta
         if use_quartet:
             q, k, v, q2, k2, mix, qs, y, saved = ctx.saved_tensors
         else:
@@ -688,6 +726,7 @@ class _QuartetFn(torch.autograd.Function):
         a.use_quartet, a.eps = int(bool(use_quartet)), float(eps)
         a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(y), _v4(dy)
         a.add_mask, (a.am_sb, a.am_sh, a.am_si) = _ptr(am), ams
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         n = 5 if use_quartet else 3
         gs = [torch.empty(B, T, H, dh, dtype=q.dtype, device=dev) for _ in range(n)]
         a.dq, a.dk_, a.dv = _v4(gs[0]), _v4(gs[1]), _v4(gs[2])
@@ -705,13 +744,15 @@ class _QuartetFn(torch.autograd.Function):
         L.check(rc, "mopk_quartet_bwd")
         if use_quartet:
             return (gs[0], gs[1], gs[2], gs[3], gs[4], dmix.sum().reshape(1), dqs.sum().reshape(1),
-                    None, None, None, None, None, None)
-        return (gs[0], gs[1], gs[2], None, None, None, None, None, None, None, None, None, None)
+                    None, None, None, None, None, None, None)
+        return (gs[0], gs[1], gs[2], None, None, None, None, None, None, None, None, None, None, None)
 
 
-def quartet_core(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights=False):
+def quartet_core(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights=False,
+                 dropout_p: float = 0.0, seed: Optional[int] = None):
+    drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     return _QuartetFn.apply(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights,
-                            _prec_for(q.dtype), _PATH)
+                            _prec_for(q.dtype), _PATH, drop)
 
 
 # ---- LayerNorm prologue / residual epilogue around the cores (mopk_layernorm_*) ----

@@ -37,8 +37,9 @@ def _znorm_bwd(dz, z, sd, eps):
 
 
 def core_fwd(q, k, v, q2, k2, mixture, quartet_scale, eps=1e-5, use_quartet=True, causal=True,
-             add_mask=None):
-    """q..: (B,H,T,dh). mixture/quartet_scale: scalars. add_mask: additive, broadcastable."""
+             add_mask=None, drop=None):
+    """q..: (B,H,T,dh). mixture/quartet_scale: scalars. add_mask: additive, broadcastable.
+    drop: None or the dropout multiplier keep / (1 - p) per edge (`self.attn_dropout(att)` :119 with the mask made explicit)."""
     dh = q.shape[-1]
     scale = 1.0 / math.sqrt(dh)
     T = q.shape[-2]
@@ -59,15 +60,18 @@ def core_fwd(q, k, v, q2, k2, mixture, quartet_scale, eps=1e-5, use_quartet=True
     if add_mask is not None:
         scores = scores + add_mask                                # :115-116
     P = _masked_softmax(scores, blocked)
-    y = np.matmul(P, v)
-    c.update(P=P)
+    Pd = P if drop is None else P * drop
+    y = np.matmul(Pd, v)
+    c.update(P=P, Pd=Pd, drop=drop)
     return y, c
 
 
 def core_bwd(dy, c):
     P = c["P"]
     dP = np.matmul(dy, np.swapaxes(c["v"], -1, -2))
-    dv = np.matmul(np.swapaxes(P, -1, -2), dy)
+    if c.get("drop") is not None:
+        dP = dP * c["drop"]
+    dv = np.matmul(np.swapaxes(c.get("Pd", P), -1, -2), dy)
     dsc = P * (dP - (P * dP).sum(-1, keepdims=True))
     out = dict(dv=dv)
     if c["use_quartet"]:

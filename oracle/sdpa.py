@@ -15,7 +15,9 @@ from .edgewise import _heads
 from .multihop import _masked_softmax
 
 
-def core_fwd(q, k, v, blocked=None, bias=None):
+def core_fwd(q, k, v, blocked=None, bias=None, drop=None):
+    """drop: None or the dropout multiplier keep / (1 - p) per edge, broadcastable to (B,H,N,N): `self.attn_drop(A)` of
+    attention_variants.py:45 / components.py:62 / whisper_mop.py:172 with the mask made explicit"""
     dk = q.shape[-1]
     scale = 1.0 / math.sqrt(dk)
     S = np.matmul(q, np.swapaxes(k, -1, -2)) * scale
@@ -24,14 +26,17 @@ def core_fwd(q, k, v, blocked=None, bias=None):
     if blocked is not None:
         blocked = np.broadcast_to(blocked, S.shape)
     P = _masked_softmax(S, blocked)
-    y = np.matmul(P, v)
-    return y, dict(q=q, k=k, v=v, P=P, scale=scale)
+    Pd = P if drop is None else P * drop
+    y = np.matmul(Pd, v)
+    return y, dict(q=q, k=k, v=v, P=P, Pd=Pd, drop=drop, scale=scale)
 
 
 def core_bwd(dy, c):
     P = c["P"]
     dP = np.matmul(dy, np.swapaxes(c["v"], -1, -2))
-    dv = np.matmul(np.swapaxes(P, -1, -2), dy)
+    if c.get("drop") is not None:
+        dP = dP * c["drop"]
+    dv = np.matmul(np.swapaxes(c.get("Pd", P), -1, -2), dy)
     dS = P * (dP - (P * dP).sum(-1, keepdims=True)) * c["scale"]
     return dict(dq=np.matmul(dS, c["k"]), dk=np.matmul(np.swapaxes(dS, -1, -2), c["q"]), dv=dv)
 

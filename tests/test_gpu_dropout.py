@@ -1,0 +1,119 @@
+"""-m gpu: attention dropout inside the fused SDPA / Quartet kernels (reference: `self.attn_drop(A)` attention_variants.py:45,
+components.py:62, whisper_mop.py:172; `self.attn_dropout(att)` quartet_attn_patch.py:119).  The mask is a counter-based function of
+(seed, b, h, query, key) that `mop_amd.ops.dropout_keep_mask` restates on the host, so values and gradients are compared with the
+oracle run under exactly the same mask; the reference's own RNG stream is not reproducible, its semantics (keep / (1 - p) on the
+probabilities after the softmax) are."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import max_abs, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _bhnd(t):                      # (B,N,H,d) torch -> (B,H,N,d) float64 numpy
+    return t.detach().float().cpu().numpy().transpose(0, 2, 1, 3).astype(np.float64)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("N,dk,p", [(197, 64, 0.1), (70, 32, 0.5), (300, 64, 0.25)])
+def test_sdpa_dropout_matches_the_oracle_under_the_same_mask(N, dk, p, causal):
+    from mop_amd import ops
+    from oracle import sdpa as O
+    torch.manual_seed(N + dk)
+    B, H, seed = 2, 3, 0xC0FFEE1234567
+    q, k, v = (torch.randn(B, N, H, dk, device="cuda", dtype=torch.bfloat16).requires_grad_(True) for _ in range(3))
+    w = torch.randn(B, N, H * dk, device="cuda", dtype=torch.bfloat16)
+    y = ops.sdpa_core(q, k, v, causal=causal, dropout_p=p, seed=seed)
+    assert ops.LAST_PATH["sdpa_fwd"] == 2
+    y.backward(w)
+    torch.cuda.synchronize()
+    keep = ops.dropout_keep_mask(seed, p, B, H, N).numpy()
+    drop = keep.astype(np.float64) / (1.0 - p)
+    blocked = np.broadcast_to(~np.tril(np.ones((N, N), dtype=bool)), (B, H, N, N)) if causal else None
+    yr, c = O.core_fwd(_bhnd(q), _bhnd(k), _bhnd(v), blocked, None, drop)
+    g = O.core_bwd(w.float().cpu().numpy().reshape(B, N, H, dk).transpose(0, 2, 1, 3).astype(np.float64), c)
+    got = y.detach().float().cpu().numpy().reshape(B, N, H, dk).transpose(0, 2, 1, 3)
+    assert max_abs(got, yr) <= 1e-2 * max(1.0, float(np.abs(yr).max())), max_abs(got, yr)
+    for name, t in (("dq", q), ("dk", k), ("dv", v)):
+        assert rel_err(_bhnd(t.grad), g[name]) <= 3e-2, (name, rel_err(_bhnd(t.grad), g[name]))
+    # the mask really bites: the undropped output differs
+    y0 = ops.sdpa_core(q, k, v, causal=causal)
+    assert float((y0 - y).detach().abs().max()) > 1e-2
+
+
+def test_sdpa_dropout_is_reproducible_and_unbiased():
+    from mop_amd import ops
+    torch.manual_seed(1)
+    B, N, H, dk = 2, 128, 4, 64
+    q, k, v = (torch.randn(B, N, H, dk, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    with torch.no_grad():
+        a = ops.sdpa_core(q, k, v, dropout_p=0.2, seed=11)
+        b = ops.sdpa_core(q, k, v, dropout_p=0.2, seed=11)
+        c = ops.sdpa_core(q, k, v, dropout_p=0.2, seed=12)
+        y0 = ops.sdpa_core(q, k, v).float()
+        mean = torch.stack([ops.sdpa_core(q, k, v, dropout_p=0.2, seed=100 + s).float() for s in range(64)]).mean(0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert float((mean - y0).abs().max()) <= 0.15 * float(y0.abs().max())          # E[dropout(P)] = P
+    torch.manual_seed(5)
+    s1 = ops.dropout_seed()
+    torch.manual_seed(5)
+    assert ops.dropout_seed() == s1                                                 # torch.manual_seed reproduces the draw
+
+
+def test_modules_train_with_attention_dropout():
+    """the module-level contract: training mode applies dropout (outputs differ between calls and from eval), eval does not"""
+    from mop_amd.nn import BaselineMSA, CausalSelfAttention, TransformerConfig
+    from mop_amd.nn.components import MSA
+    from mop_amd.nn.whisper_mop import MultiheadSelfAttention
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 128, device="cuda", dtype=torch.bfloat16)
+    mods = [BaselineMSA(128, 4, attn_drop=0.2), MSA(128, 4, attn_drop=0.2), MultiheadSelfAttention(128, 4, 0.2, False, causal=False),
+            CausalSelfAttention(TransformerConfig(n_head=4, n_embd=128, block_size=64, dropout=0.2))]
+    for m in mods:
+        m = m.cuda().to(torch.bfloat16)
+        for d in m.modules():                                   # isolate the attention dropout: residual / projection dropouts off
+            if isinstance(d, torch.nn.Dropout) and d is not getattr(m, "attn_drop", None):
+                d.p = 0.0
+        m.eval()
+        with torch.no_grad():
+            e1, e2 = m(x), m(x)
+        assert torch.equal(e1, e2)
+        m.train()
+        xi = x.clone().requires_grad_(True)
+        t1 = m(xi)
+        t1.float().square().sum().backward()
+        with torch.no_grad():
+            t2 = m(x)
+        assert not torch.equal(t1.detach(), t2) and not torch.equal(t1.detach(), e1), type(m).__name__
+        assert torch.isfinite(xi.grad).all() and float(xi.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("use_quartet", [True, False])
+def test_quartet_dropout_matches_the_oracle_under_the_same_mask(use_quartet):
+    from mop_amd import ops
+    from oracle import quartet as O
+    torch.manual_seed(3)
+    B, T, H, dh, p, seed = 2, 160, 3, 64, 0.2, 987654321012345
+    ts = [torch.randn(B, T, H, dh, device="cuda", dtype=torch.bfloat16).requires_grad_(True) for _ in range(5)]
+    q, k, v, q2, k2 = ts
+    mix = torch.tensor([0.3], device="cuda", requires_grad=True)
+    qs = torch.tensor([1.2], device="cuda", requires_grad=True)
+    w = torch.randn(B, T, H * dh, device="cuda", dtype=torch.bfloat16)
+    y = ops.quartet_core(q, k, v, q2 if use_quartet else None, k2 if use_quartet else None, mix, qs, None, 1e-5, use_quartet,
+                         dropout_p=p, seed=seed)
+    assert ops.LAST_PATH["quartet_fwd"] == 2
+    y.backward(w)
+    torch.cuda.synchronize()
+    drop = ops.dropout_keep_mask(seed, p, B, H, T).numpy().astype(np.float64) / (1.0 - p)
+    yr, c = O.core_fwd(_bhnd(q), _bhnd(k), _bhnd(v), _bhnd(q2), _bhnd(k2), float(mix), float(qs), 1e-5, use_quartet, True, None, drop)
+    g = O.core_bwd(w.float().cpu().numpy().reshape(B, T, H, dh).transpose(0, 2, 1, 3).astype(np.float64), c)
+    got = y.detach().float().cpu().numpy().reshape(B, T, H, dh).transpose(0, 2, 1, 3)
+    assert max_abs(got, yr) <= 1e-2 * max(1.0, float(np.abs(yr).max())), max_abs(got, yr)
+    names = [("dq", q), ("dk", k), ("dv", v)] + ([("dq2", q2), ("dk2", k2)] if use_quartet else [])
+    for name, t in names:
+        assert rel_err(_bhnd(t.grad), g[name]) <= 4e-2, (name, rel_err(_bhnd(t.grad), g[name]))
+    if use_quartet:
+        assert abs(float(mix.grad) - float(g["dmixture"])) <= 5e-2 * max(abs(float(g["dmixture"])), 1e-3)
+        assert abs(float(qs.grad) - float(g["dquartet_scale"])) <= 5e-2 * max(abs(float(g["dquartet_scale"])), 1e-3)

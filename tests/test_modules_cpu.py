@@ -96,16 +96,30 @@ def test_unsupported_variants_raise_instead_of_falling_back():
         EdgewiseMSA(64, 4, gate_mode="dense")(x)
 
 
-def test_attention_dropout_in_training_raises_in_every_module():
-    """the reference applies attn_drop to the attention weights (attention_variants.py:45, :153, :222, :552); the kernels do not,
-    so every module refuses the configuration instead of silently training a different model."""
-    from mop_amd.nn import BaselineMSA, CrossViewMixerMSA, EdgewiseMSA, MultiHopMSA
+def test_attention_dropout_in_training_raises_where_the_kernels_do_not_carry_it():
+    """the reference applies attn_drop to the attention weights (attention_variants.py:45, :153, :222, :552).  The fused SDPA and
+    Quartet kernels carry it (BaselineMSA, MSA, Whisper's MultiheadSelfAttention, CausalSelfAttention: tests/test_gpu_dropout.py);
+    the other cores do not, and refuse the configuration instead of silently training a different model."""
+    from mop_amd.nn import CrossViewMixerMSA, EdgewiseMSA, MultiHopMSA
     x = torch.randn(1, 8, 64)
-    for cls, kw in ((BaselineMSA, {}), (MultiHopMSA, {}), (CrossViewMixerMSA, {}),
-                    (EdgewiseMSA, dict(gate_mode="lowrank", share_qkv=True))):
+    for cls, kw in ((MultiHopMSA, {}), (CrossViewMixerMSA, {}), (EdgewiseMSA, dict(gate_mode="lowrank", share_qkv=True))):
         m = cls(64, 4, attn_drop=0.1, **kw).train()
         with pytest.raises(NotImplementedError, match="attn_drop"):
             m(x)
+
+
+def test_dropout_mask_restatement_matches_the_library():
+    """`ops.dropout_keep_mask` (numpy) == `mopk_dropout_keep` (the C function the kernels share their hash with), and its keep rate"""
+    from mop_amd import _lib as L, ops
+    seed, p, B, H, N = 0x1234_5678_9ABC_DEF, 0.3, 2, 3, 37
+    m = ops.dropout_keep_mask(seed, p, B, H, N)
+    lib = L.lib()
+    for bh, i, j in ((0, 0, 0), (5, 36, 1), (3, 17, 36), (1, 2, 3), (4, 30, 30)):
+        assert bool(m[bh // H, bh % H, i, j]) == bool(lib.mopk_dropout_keep(seed, p, bh, i, j))
+    big = ops.dropout_keep_mask(7, 0.1, 4, 4, 256).float()
+    assert abs(float(big.mean()) - 0.9) < 2e-3
+    assert abs(float(big.mean(dim=-1).std()) - (0.1 * 0.9 / 256) ** 0.5) < 5e-3          # rows are independent draws
+    assert bool(ops.dropout_keep_mask(7, 0.0, 1, 1, 8).all()) and lib.mopk_dropout_keep(7, 0.0, 0, 1, 2) == 1
 
 
 def test_causal_mask_detection_is_keyed_by_tensor_identity_not_address():
