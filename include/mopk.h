@@ -137,6 +137,8 @@ typedef struct MopkEdgewiseArgs {
     float *dlogit_part;      /* out: (B,H) */
 
     const MopkEdgewiseExt *ext; /* host pointer; NULL = low-rank head without lens bank (the only form the fused path takes) */
+    float dropout_p;         /* attn_drop on the mixed attention weights (:552), fused path only; see MopkSdpaArgs.dropout_p */
+    uint64_t dropout_seed;
 } MopkEdgewiseArgs;
 
 size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a);

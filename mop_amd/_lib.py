@@ -50,6 +50,7 @@ class EdgewiseArgs(C.Structure):
         ("dsqk_part", _fp), ("dvs0_part", _fp), ("dvsL_part", _fp),
         ("dWr", _fp), ("dbr", _fp), ("dWc", _fp), ("dbc", _fp), ("dlogit_part", _fp),
         ("ext", C.POINTER(EdgewiseExt)),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
     ]
 
 

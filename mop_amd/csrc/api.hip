@@ -31,6 +31,7 @@ int qt_fwd(const MopkQuartetArgs *a, hipStream_t st); int qt_bwd(const MopkQuart
 
 static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
     if (!a) return MOPK_ERR_BAD_ARG;
+    if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (a->B <= 0 || a->H <= 0 || a->N <= 0 || a->dk <= 0 || a->V < 2 || a->r < 1) return MOPK_ERR_BAD_SHAPE;
     if (a->io_dtype != MOPK_F32 && a->io_dtype != MOPK_BF16) return MOPK_ERR_BAD_ARG;
     if (a->precision != MOPK_PREC_FP32 && a->precision != MOPK_PREC_BF16) return MOPK_ERR_BAD_ARG;
@@ -104,12 +105,14 @@ int mopk_edgewise_fwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, false);
     if (rc) return rc;
     if (a->path == MOPK_PATH_FUSED) return ew_fused_fwd(a, (hipStream_t)stream);
+    if (a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;          // attention dropout lives in the fused kernels only
     return ew_generic_fwd(a, (hipStream_t)stream);
 }
 int mopk_edgewise_bwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, true);
     if (rc) return rc;
     if (a->path == MOPK_PATH_FUSED) return ew_fused_bwd(a, (hipStream_t)stream);
+    if (a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;
     return ew_generic_bwd(a, (hipStream_t)stream);
 }
 int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {

@@ -596,12 +596,18 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     mxrow = fmaxf(mxrow, __shfl_xor(mxrow, 32, 64));
     float l = 0.f;
     bf16x8 Pp[NT][2];
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);      // attn_drop (:552): keep / (1 - p) on P; the row sum stays undropped
+    const uint32_t rowh = fa_drop_row(drop, b * H + hh, qi);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const float e0 = __expf(h2_lo(crp[t][p]) - mxrow), e1 = __expf(h2_hi(crp[t][p]) - mxrow);
+            float e0 = __expf(h2_lo(crp[t][p]) - mxrow), e1 = __expf(h2_hi(crp[t][p]) - mxrow);
             l += e0 + e1;
+            if (drop.thresh) {
+                e0 = fa_drop_keep(drop, rowh, 32 * t + tile_row(2 * p, h)) ? e0 * drop.inv_keep : 0.f;
+                e1 = fa_drop_keep(drop, rowh, 32 * t + tile_row(2 * p + 1, h)) ? e1 * drop.inv_keep : 0.f;
+            }
             Pp[t][p >> 2][2 * (p & 3)] = (short)f2bf(e0);
             Pp[t][p >> 2][2 * (p & 3) + 1] = (short)f2bf(e1);
         }

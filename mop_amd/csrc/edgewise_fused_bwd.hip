@@ -579,6 +579,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
         delta = d + __shfl_xor(d, 32, 64);
     }
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t rowh = fa_drop_row(drop, bh, qi);
     auto p_tile = [&](int t) -> f32x16 {      // P tile from the parked Smix
         const u32x4 *p = slot(S_SM);
         f32x16 x = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), __builtin_nontemporal_load(&p[(2 * t + 1) * 64]));
@@ -608,7 +610,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         make_frag(dyf_t, dyrow, nullptr);
         {
             const f32x16 P = p_tile(t);
-            const f32x16 dP = g_tile(V0s, dyf_t, t);
+            f32x16 dP = g_tile(V0s, dyf_t, t);
+            if (drop.thresh) {                 // attn_drop: dP = (dy v0^T) keep / (1 - p); delta = dy . y_base already carries it
+#pragma unroll
+                for (int g = 0; g < 16; ++g) dP[g] = fa_drop_keep(drop, rowh, 32 * t + tile_row(g, h)) ? dP[g] * drop.inv_keep : 0.f;
+            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) dS[g] = (32 * t + tile_row(g, h) < N) ? P[g] * (dP[g] - delta) : 0.f;
         }
@@ -797,7 +803,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     {
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            const f32x16 P = p_tile(t);
+            f32x16 P = p_tile(t);
+            if (drop.thresh) {                 // dv0 sees the dropped probabilities
+#pragma unroll
+                for (int g = 0; g < 16; ++g) P[g] = fa_drop_keep(drop, rowh, 32 * t + tile_row(g, h)) ? P[g] * drop.inv_keep : 0.f;
+            }
             bf16x8 lo, hi;
             pack_tile_bf(lo, hi, P);
             store_i_tile(R, t, lo, hi);

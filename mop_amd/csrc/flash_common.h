@@ -7,28 +7,6 @@ namespace {   // internal linkage: each translation unit gets its own copies
 constexpr int FA_NW = 4, FA_QB = 32 * FA_NW, FA_KT = 64, FA_LDT = FA_KT + 8;
 constexpr float FA_NEG = -1e30f, FA_LOG2E = 1.4426950408889634f, FA_LN2 = 0.6931471805599453f;
 
-// ---- attention dropout: counter-based keep mask, a pure function of (seed, b*H+h, query, key) -- evaluated again in the backward
-__host__ __device__ __forceinline__ uint32_t fa_hash(uint32_t x) {          // "lowbias32" integer finalizer
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-struct FaDrop { uint32_t thresh, seed_lo, seed_hi; float inv_keep; };      // thresh == 0: dropout off
-__host__ __device__ __forceinline__ FaDrop fa_drop(float p, uint64_t seed) {
-    FaDrop d{0u, (uint32_t)seed, (uint32_t)(seed >> 32), 1.f};
-    if (p > 0.f) {
-        const double t = (double)p * 4294967296.0;
-        d.thresh = t >= 4294967295.0 ? 0xffffffffu : (t < 1.0 ? 1u : (uint32_t)t);
-        d.inv_keep = 1.f / (1.f - p);
-    }
-    return d;
-}
-__host__ __device__ __forceinline__ uint32_t fa_drop_row(const FaDrop &d, int bh, int i) {
-    return fa_hash((uint32_t)i * 0x9E3779B1u + (uint32_t)bh * 0x85EBCA77u + d.seed_hi) ^ d.seed_lo;
-}
-__host__ __device__ __forceinline__ bool fa_drop_keep(const FaDrop &d, uint32_t rowh, int j) {
-    return fa_hash(rowh ^ ((uint32_t)j * 0xC2B2AE3Du)) >= d.thresh;
-}
-
 __device__ __forceinline__ f32x16 fa_zero() { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
 __device__ __forceinline__ void fa_pack(bf16x8 &lo, bf16x8 &hi, const f32x16 &x) {
 #pragma unroll

@@ -171,8 +171,9 @@ class EdgewiseMSA(nn.Module):
         if self.use_lens_bank and self.lens_kernel_size != 3:
             raise ValueError("lens_kernel_size must be 3: with padding = dilation any other size changes the plane size and "
                              "the reference's feature stack (:534) cannot be built")
-        if self.training and (self.attn_drop.p > 0):
-            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+        if self.training and self.attn_drop.p > 0 and (self.edge_head.gate_mode == "dense" or self.use_lens_bank):
+            raise NotImplementedError("attn_drop > 0 in training mode: the fused low-rank kernels carry it, the dense-head / "
+                                      "lens-bank variants (generic path) do not")
 
     def _qk_lens_views(self, qkv: torch.Tensor) -> torch.Tensor:
         """Q/K lens bank (:472-498): depthwise dilated convolutions over the token axis of view-0 q and k build one
@@ -231,7 +232,8 @@ class EdgewiseMSA(nn.Module):
         if not dense and not self.use_lens_bank:
             y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,
                                           eh.col_proj.weight.squeeze(-1), eh.col_proj.bias,
-                                          self.chain_value_logit, float(self.beta_not), n_s)
+                                          self.chain_value_logit, float(self.beta_not), n_s,
+                                          dropout_p=float(self.attn_drop.p) if self.training else 0.0)      # :552
             return self._project(y, residual)
         # dense gate head and / or S lens bank: the library's generic path (MopkEdgewiseExt)
         lens_w = torch.stack([c.weight[:, 0] for c in self.lens_bank]) if self.use_lens_bank else None   # (L,S,3,3)

@@ -159,7 +159,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
     """y = EdgewiseMSA core(qkv, ...) ; reference attention_variants.py:500-562."""
 
     @staticmethod
-    def forward(ctx, qkv, sqk, vs0, vsL, Wr, br, Wc, bc, logit, beta_not, V, prec, path, want_bwd):
+    def forward(ctx, qkv, sqk, vs0, vsL, Wr, br, Wc, bc, logit, beta_not, V, prec, path, want_bwd, drop=(0.0, 0)):
         _require_gpu(qkv, "EdgewiseMSA")
         lib = L.lib()
         B, N, Vq, _, H, dk = qkv.shape
@@ -182,6 +182,10 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         if path == L.PATH_AUTO:   # AUTO: fused gfx950 kernels when they cover the shape, generic otherwise
             path = L.PATH_FUSED if lib.mopk_edgewise_fused_supported(C.byref(a)) else L.PATH_GENERIC
         a.path = path
+        if drop[0] > 0 and path != L.PATH_FUSED:
+            raise NotImplementedError("attn_drop > 0 in training mode runs in the fused bf16 Edgewise kernels only (low-rank head, "
+                                      "shared qkv, N <= 224, dk 16/32/64, bf16 arithmetic)")
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         # training forward of the fused path also exports the chain state its backward would otherwise recompute
         a.save_for_backward = int(bool(want_bwd) and path == L.PATH_FUSED and _SAVE_CHAIN_STATE)
         LAST_PATH["edgewise_fwd"] = path
@@ -194,14 +198,14 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
             rc = lib.mopk_edgewise_lowrank_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_lowrank_fwd")
         ctx.save_for_backward(qkv, saved, *f.values())
-        ctx.meta = (beta_not, V, prec, path, r, int(a.save_for_backward))
+        ctx.meta = (beta_not, V, prec, path, r, int(a.save_for_backward), drop)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
         qkv, saved, sqk, vs0, vsL, Wr, br, Wc, bc, logit = ctx.saved_tensors
-        beta_not, V, prec, path, r, sfb = ctx.meta
+        beta_not, V, prec, path, r, sfb, drop = ctx.meta
         B, N, Vq, _, H, dk = qkv.shape
         dev = qkv.device
         dy = dy.contiguous()
@@ -211,6 +215,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.B, a.H, a.N, a.dk, a.V, a.r = B, H, N, dk, V, r
         a.io_dtype, a.precision, a.path, a.beta_not = _io_dtype(qkv), prec, path, float(beta_not)
         a.save_for_backward = sfb
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         _ew_views(a, qkv, "")
         a.sqk, a.vs0, a.vsL = sqk.data_ptr(), vs0.data_ptr(), vsL.data_ptr()
         a.Wr, a.br, a.Wc, a.bc = Wr.data_ptr(), br.data_ptr(), Wc.data_ptr(), bc.data_ptr()
@@ -246,7 +251,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
             small = small.to(ctx.small_dtype)
             dsqk, dvs0, dvsL, dWr, dbr, dWc, dbc, dlg = torch.split(small, [n_sqk, n_vs, n_vs, n_w, n_b, n_w, n_b, 1])
         return (dqkv, dsqk.view(V, H, dk), dvs0.view(H, dk), dvsL.view(H, dk), dWr.view(4 * r, C_), dbr, dWc.view(4 * r, C_), dbc,
-                dlg.reshape(()), None, None, None, None, None)
+                dlg.reshape(()), None, None, None, None, None, None)
 
 
 class EdgewiseVariant:
@@ -369,13 +374,16 @@ def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float
 
 
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,
-                          n_views: int, precision: Optional[int] = None, path: Optional[int] = None):
-    """qkv: (B,N,Vq,3,H,dk) with Vq in {1 (share_qkv), n_views}; returns (B,N,H*dk)."""
+                          n_views: int, precision: Optional[int] = None, path: Optional[int] = None,
+                          dropout_p: float = 0.0, seed: Optional[int] = None):
+    """qkv: (B,N,Vq,3,H,dk) with Vq in {1 (share_qkv), n_views}; returns (B,N,H*dk).  dropout_p > 0: attn_drop on the mixed
+    attention weights (:552) inside the fused kernels (see `sdpa_core`)."""
+    drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     prec = _prec_for(qkv.dtype) if precision is None else precision
     want_bwd = torch.is_grad_enabled() and any(
         t.requires_grad for t in (qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit))
     return _EdgewiseLowrankFn.apply(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not,
-                                    n_views, prec, _PATH if path is None else path, want_bwd)
+                                    n_views, prec, _PATH if path is None else path, want_bwd, drop)
 
 
 # --------------------------------------------------------------------------------------

@@ -141,7 +141,7 @@ def dense_head_bwd(dZ, c, hp):
 # ----------------------------------------------------------------------------
 # attention core: everything between the qkv projection and the out projection
 # ----------------------------------------------------------------------------
-def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, lens=None):
+def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, lens=None, drop=None):
     """EdgewiseMSA.forward :500-562 for per-view queries/keys.
 
     qv, kv : (V,B,H,N,dk)  per-view q_i, k_i   (:461-470)
@@ -201,7 +201,8 @@ def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, 
     Smix = S0 + G[:, :, 0] * O + G[:, :, 1] * (lse - S0) - G[:, :, 2] * (nb * O) \
         + G[:, :, 3] * Cr                                         # :543-547
     P = _softmax(Smix, -1)                                        # :551
-    y_base = np.matmul(P, v0)                                     # :554
+    Pd = P if drop is None else P * drop                          # :552 attn_drop with the mask made explicit: drop = keep / (1 - p)
+    y_base = np.matmul(Pd, v0)                                    # :554
     t = [None] * V                                                # :557-560 value transport
     t[V - 1] = vL
     for i in range(V - 1, 0, -1):
@@ -212,7 +213,7 @@ def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, 
     cache = dict(qv=qv, kv=kv, v0=v0, vL=vL, Wr=Wr, Wc=Wc, S=S, A=A, T=T, U=U, Cf=Cf, Cb=Cb,
                  Cr=Cr, Cl=Cl, row_feat=row_feat, col_feat=col_feat, a4=a4, b4=b4, G=G,
                  lse=lse, O=O, nb=nb, P=P, t=t, y_chain=y_chain, w=w, scale=scale,
-                 Smix=Smix, a=a, b=b, y_base=y_base, dense=dense, lens=lens, hc=hc, Lz=Lz)
+                 Smix=Smix, a=a, b=b, y_base=y_base, dense=dense, lens=lens, hc=hc, Lz=Lz, Pd=Pd, drop=drop)
     return y, cache
 
 
@@ -225,7 +226,9 @@ def core_bwd(dy, c):
     # y = P v0 + w * A0 t0
     dlogit = (dy * c["y_chain"]).sum() * w * (1.0 - w)
     dP = np.matmul(dy, np.swapaxes(v0, -1, -2))
-    dv0 = np.matmul(np.swapaxes(P, -1, -2), dy)
+    if c.get("drop") is not None:
+        dP = dP * c["drop"]
+    dv0 = np.matmul(np.swapaxes(c.get("Pd", P), -1, -2), dy)
     dA = np.zeros_like(A)
     g = w * dy                                                    # grad wrt A0 t0
     t = c["t"]
@@ -358,9 +361,10 @@ def _head_params(params):
 
 
 def module_fwd(x, params: Dict[str, np.ndarray], heads: int, n_views: int, share_qkv: bool,
-               beta_not: float = 0.5, lens_dilations=None, lens_qk=None):
+               beta_not: float = 0.5, lens_dilations=None, lens_qk=None, drop=None):
     """lens_dilations: dilations of the S lens bank (params lens_bank.{l}.weight) or None;
-    lens_qk: None or (dilations, causal) for the Q/K lens bank (params q_lens.{l}.weight, k_lens.{l}.weight)."""
+    lens_qk: None or (dilations, causal) for the Q/K lens bank (params q_lens.{l}.weight, k_lens.{l}.weight);
+    drop: None or the attn_drop multiplier keep / (1 - p) per edge, (B,H,N,N) (:552 with the mask made explicit)."""
     B, N, D = x.shape
     H, dk = heads, D // heads
     V = max(2, int(n_views))                                      # :362
@@ -398,7 +402,7 @@ def module_fwd(x, params: Dict[str, np.ndarray], heads: int, n_views: int, share
     lens = None
     if lens_dilations is not None:
         lens = (np.stack([params[f"lens_bank.{l}.weight"][:, 0] for l in range(len(lens_dilations))]), tuple(lens_dilations))
-    y, cache = core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, params["chain_value_logit"], dense=dense, lens=lens)
+    y, cache = core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, params["chain_value_logit"], dense=dense, lens=lens, drop=drop)
     ycat = np.transpose(y, (0, 2, 1, 3)).reshape(B, N, D)         # :563
     out = ycat @ params["proj.weight"].T                          # :564
     cache.update(x=x, ycat=ycat, share=share_qkv, H=H, V=V, params=params, lens_qk=lens_qk, qk_ctx=qk_ctx,

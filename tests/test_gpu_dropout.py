@@ -107,7 +107,7 @@ def test_quartet_dropout_matches_the_oracle_under_the_same_mask(use_quartet):
     y.backward(w)
     torch.cuda.synchronize()
     drop = ops.dropout_keep_mask(seed, p, B, H, T).numpy().astype(np.float64) / (1.0 - p)
-    yr, c = O.core_fwd(_bhnd(q), _bhnd(k), _bhnd(v), _bhnd(q2), _bhnd(k2), float(mix), float(qs), 1e-5, use_quartet, True, None, drop)
+    yr, c = O.core_fwd(_bhnd(q), _bhnd(k), _bhnd(v), _bhnd(q2), _bhnd(k2), float(mix.detach()), float(qs.detach()), 1e-5, use_quartet, True, None, drop)
     g = O.core_bwd(w.float().cpu().numpy().reshape(B, T, H, dh).transpose(0, 2, 1, 3).astype(np.float64), c)
     got = y.detach().float().cpu().numpy().reshape(B, T, H, dh).transpose(0, 2, 1, 3)
     assert max_abs(got, yr) <= 1e-2 * max(1.0, float(np.abs(yr).max())), max_abs(got, yr)
@@ -117,3 +117,56 @@ def test_quartet_dropout_matches_the_oracle_under_the_same_mask(use_quartet):
     if use_quartet:
         assert abs(float(mix.grad) - float(g["dmixture"])) <= 5e-2 * max(abs(float(g["dmixture"])), 1e-3)
         assert abs(float(qs.grad) - float(g["dquartet_scale"])) <= 5e-2 * max(abs(float(g["dquartet_scale"])), 1e-3)
+
+
+@pytest.mark.parametrize("save_chain", [True, False])
+def test_edgewise_dropout_matches_the_oracle_under_the_same_mask(save_chain):
+    """EdgewiseMSA(lowrank) in training mode with attn_drop (:552) on the fused kernels; both backward modes (saved chain state /
+    forward re-run inside the backward, which must reproduce the same mask)."""
+    import mop_amd
+    from mop_amd import ops
+    from mop_amd.nn import EdgewiseMSA
+    from oracle import edgewise as O
+    from gpu_util import check_grads, oracle_bf16_noise
+    D, Hh, V, N, B, p = 128, 2, 3, 50, 3, 0.2
+    torch.manual_seed(21)
+    m = EdgewiseMSA(D, Hh, attn_drop=p, n_views=V, share_qkv=True, gate_mode="lowrank", gate_rank=2, gate_init="mix5")
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.add_(0.1 * torch.randn_like(prm))
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    x = torch.randn(B, N, D)
+    w = torch.randn(B, N, D)
+    mop_amd.set_precision("bf16")
+    ops.set_save_chain_state(save_chain)
+    try:
+        mg = m.cuda().to(torch.bfloat16).train()
+        xg = x.cuda().to(torch.bfloat16).requires_grad_(True)
+        torch.manual_seed(77)
+        seed = ops.dropout_seed()
+        torch.manual_seed(77)                              # the module draws exactly this seed
+        y = mg(xg)
+        assert ops.LAST_PATH["edgewise_fwd"] == 2
+        y.backward(w.cuda().to(torch.bfloat16))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_save_chain_state(True)
+        mop_amd.set_precision("auto")
+    drop = ops.dropout_keep_mask(seed, p, B, Hh, N).numpy().astype(np.float64) / (1.0 - p)
+    fwd = lambda xx, pp, *a: O.module_fwd(xx, pp, *a, drop=drop)
+    rb = lambda t: torch.as_tensor(t).to(torch.bfloat16).double().numpy()       # what the kernels were given
+    yr, cb = fwd(rb(x), {k: rb(v) for k, v in params.items()}, Hh, V, True, 0.5)
+    dxr, _ = O.module_bwd(rb(w), cb)
+    assert max_abs(y.detach().float().cpu().numpy(), yr) <= 1e-2 * max(1.0, float(np.abs(yr).max()))
+    assert rel_err(xg.grad.float().cpu().numpy(), dxr) <= 3e-2
+    _, c = fwd(x.double().numpy(), params, Hh, V, True, 0.5)
+    _, gr = O.module_bwd(w.double().numpy(), c)
+    grads = {k: v.grad.detach().float().cpu().numpy() for k, v in mg.named_parameters()}
+    # per tensor 3e-2, or 4 x the amount the exact gradient itself moves when the inputs are rounded to bf16 (gate-head gradients are
+    # differences of N^2 terms, with or without dropout: DESIGN.md section 5 "Accuracy")
+    noise = oracle_bf16_noise(fwd, O.module_bwd, x.numpy(), w.numpy(), params, Hh, V, True, 0.5)
+    check_grads(grads, gr, 3e-2, d=noise)
+    with torch.no_grad():                                   # eval mode ignores attn_drop
+        mg.eval()
+        e1, e2 = mg(xg), mg(xg)
+    assert torch.equal(e1, e2)
