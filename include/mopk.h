@@ -173,6 +173,9 @@ typedef struct MopkDualPathArgs {
     /* backward */
     MopkView4 dy, dq1, dk1, dv1, dq2, dk2, dv2;
     float *dlogit_part;      /* (B,H) */
+    float dropout_p;         /* attn_drop on the mixed attention weights (attention_variants.py:222; the transport term uses the
+                              * undropped A1, A2 :224-227); fused path only, see MopkSdpaArgs.dropout_p */
+    uint64_t dropout_seed;
 } MopkDualPathArgs;
 
 size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a);

@@ -65,6 +65,7 @@ class DualPathArgs(C.Structure):
         ("chain_logit", _fp), ("y", View4), ("saved", _fp), ("workspace", _fp),
         ("dy", View4), ("dq1", View4), ("dk1", View4), ("dv1", View4), ("dq2", View4), ("dk2", View4),
         ("dv2", View4), ("dlogit_part", _fp),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
     ]
 
 

@@ -196,8 +196,9 @@ int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream) {
     if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !v4ok(a->y) || !a->saved || !a->workspace)
         return MOPK_ERR_BAD_ARG;
     if (a->hops > 0 && (!v4ok(a->v2) || !a->chain_logit)) return MOPK_ERR_BAD_ARG;
+    if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (dp_use_flash(a)) return dp_flash_fwd(a, (hipStream_t)stream);
-    if (a->path == MOPK_PATH_FUSED || a->hops == 0) return MOPK_ERR_UNSUPPORTED;     // hops == 0 exists on the fused kernels only
+    if (a->path == MOPK_PATH_FUSED || a->hops == 0 || a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;   // hops == 0 and dropout exist on the fused kernels only
     return dp_fwd(a, (hipStream_t)stream);
 }
 int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream) {

@@ -528,6 +528,7 @@ int dp_flash_fwd(const MopkDualPathArgs *a, hipStream_t st) {
     {   // mixed logits: S1 + a2 S2 + g_or (lse - S1)                                           :209-213, :219-221
         MopkSdpaArgs s = dp_sdpa(a);
         s.q = a->q1; s.k = a->k1; s.v = a->v1; s.y = o1;
+        s.dropout_p = a->dropout_p; s.dropout_seed = a->dropout_seed;             // attn_drop on the mixed weights only (:222)
         FaDual u{a->q2, a->k2, MopkView4{}, MopkView4{}, a->g_and - a->beta_not * a->g_not, a->g_or};
         const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
         const MopkSdpaArgs *keep = a ? &s : nullptr;
@@ -563,6 +564,7 @@ int dp_flash_bwd(const MopkDualPathArgs *a, hipStream_t st) {
     {   // mixed-logit pass: dq1, dk1, dv1, dq2, dk2 straight into the caller's tensors
         MopkSdpaArgs s = dp_sdpa(a);
         s.q = a->q1; s.k = a->k1; s.v = a->v1; s.y = o1; s.dy = a->dy; s.dq = a->dq1; s.dk_ = a->dk1; s.dv = a->dv1;
+        s.dropout_p = a->dropout_p; s.dropout_seed = a->dropout_seed;
         FaDual u{a->q2, a->k2, a->dq2, a->dk2, a->g_and - a->beta_not * a->g_not, a->g_or};
         const int64_t rows = (int64_t)a->B * a->H * a->N;
         if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, s, W.delta);

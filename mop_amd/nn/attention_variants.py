@@ -288,8 +288,7 @@ class MultiHopMSA(nn.Module):
         self.chain_value_logit = nn.Parameter(torch.tensor(-2.0))
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.training and self.attn_drop.p > 0:       # reference :222 applies dropout to the mixed attention weights
-            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+        pdrop = float(self.attn_drop.p) if self.training else 0.0      # reference :222: dropout on the mixed attention weights
         B, N, D = x.shape
         qkv1 = self.qkv1(x).view(B, N, 3, self.h, self.dk)
         qkv2 = self.qkv2(x).view(B, N, 3, self.h, self.dk)
@@ -298,7 +297,7 @@ class MultiHopMSA(nn.Module):
         y = ops.dualpath_core(qkv1[:, :, 0], qkv1[:, :, 1], qkv1[:, :, 2], qkv2[:, :, 0], qkv2[:, :, 1], qkv2[:, :, 2],
                               self.chain_value_logit, g.get("and_", 1.0), g.get("or_", 0.0),
                               g.get("not_", 0.0), g.get("chain", 0.0), self.beta_not, self.hops,
-                              None if causal else attn_mask, causal=causal)
+                              None if causal else attn_mask, causal=causal, dropout_p=pdrop)
         return self.proj_drop(self.proj(y))
 
 
@@ -323,8 +322,7 @@ class CrossViewMixerMSA(nn.Module):
         self.anchor_mode, self.fixed_k_star = str(anchor_mode), int(fixed_k_star)
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.training and self.attn_drop.p > 0:
-            raise NotImplementedError("attn_drop > 0 in training mode is not supported by the kernels yet")
+        pdrop = float(self.attn_drop.p) if self.training else 0.0      # reference :153, carried by the fused path only
         B, N, D = x.shape
         a = self.qkv1(x).view(B, N, 3, self.h, self.dk)
         b = self.qkv2(x).view(B, N, 3, self.h, self.dk)           # v2 is unused by the reference too (:98)
@@ -334,7 +332,7 @@ class CrossViewMixerMSA(nn.Module):
         y = ops.crossview_core(a[:, :, 0], a[:, :, 1], a[:, :, 2], b[:, :, 0], b[:, :, 1], self.mix,
                                t1=self.t1 if cues else 0.0, t2=self.t2 if cues else 0.0, prior_weight=pw,
                                anchor_mode=self.anchor_mode, fixed_k_star=self.fixed_k_star,
-                               attn_mask=None if causal else attn_mask, causal=causal)
+                               attn_mask=None if causal else attn_mask, causal=causal, dropout_p=pdrop)
         return self.proj_drop(self.proj(y))
 
 

@@ -583,9 +583,10 @@ class _CrossViewFn(torch.autograd.Function):
 
 
 def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, anchor_mode="argmax_row_sum", fixed_k_star=0,
-                   attn_mask=None, causal=False):
+                   attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
     """q*,k*,v1: (B,N,H,dk) views; mix (2,2).  prior_weight = 0 disables the per-key prior.  Returns (B,N,H*dk)."""
     prec = _prec_for(q1.dtype)
+    drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     if (prior_weight <= 0.0 and t1 == 0.0 and t2 == 0.0 and attn_mask is None and _PATH != L.PATH_GENERIC and prec == L.PREC_BF16
             and q1.shape[-1] in (32, 64)):
         # S = q1 (m11 k1 + m12 k2)^T + q2 (m21 k1 + m22 k2)^T: the 2x2 mix folds into two mixed key tensors (autograd carries
@@ -595,7 +596,10 @@ def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, an
         k2p = (m[1, 0] * k1 + m[1, 1] * k2).contiguous()
         zero = q1.new_zeros((), dtype=torch.float32)
         LAST_PATH["crossview_fwd"] = L.PATH_FUSED
-        return _DualPathFn.apply(q1, k1p, v1, q2, k2p, v1, zero, (1.0, 0.0, 0.0, 0.0), 0.0, 0, None, causal, prec, L.PATH_FUSED)
+        return _DualPathFn.apply(q1, k1p, v1, q2, k2p, v1, zero, (1.0, 0.0, 0.0, 0.0), 0.0, 0, None, causal, prec, L.PATH_FUSED, drop)
+    if drop[0] > 0:
+        raise NotImplementedError("attn_drop > 0 in training mode: CrossViewMixerMSA carries it on its fused path only (no transpose "
+                                  "cues, no per-key prior, no mask tensor, bf16 arithmetic, dk 32/64)")
     LAST_PATH["crossview_fwd"] = L.PATH_GENERIC
     cfg = (float(t1), float(t2), float(prior_weight), int(prior_weight > 0.0), _ANCHOR_MODES.get(anchor_mode, 2), int(fixed_k_star))
     return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, prec)
@@ -603,7 +607,7 @@ def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, an
 
 class _DualPathFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q1, k1, v1, q2, k2, v2, logit, gates, beta_not, hops, mask, causal, prec, path):
+    def forward(ctx, q1, k1, v1, q2, k2, v2, logit, gates, beta_not, hops, mask, causal, prec, path, drop=(0.0, 0)):
         _require_gpu(q1, "MultiHopMSA")
         lib = L.lib()
         ts = [_heads_view(t) for t in (q1, k1, v1, q2, k2, v2)]
@@ -624,6 +628,10 @@ class _DualPathFn(torch.autograd.Function):
         if path == L.PATH_AUTO:
             path = L.PATH_FUSED if lib.mopk_dualpath_fused_supported(C.byref(a)) else L.PATH_GENERIC
             a.path = path
+        if drop[0] > 0 and path != L.PATH_FUSED:
+            raise NotImplementedError("attn_drop > 0 in training mode runs in the fused bf16 kernels only (dk 32/64, chain gate 0, "
+                                      "no mask tensor, bf16 arithmetic)")
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         LAST_PATH["dualpath_fwd"] = path
         saved = _bytes(lib.mopk_dualpath_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
@@ -632,14 +640,14 @@ class _DualPathFn(torch.autograd.Function):
             rc = lib.mopk_dualpath_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_dualpath_fwd")
         ctx.save_for_backward(*ts, lg, y, saved)
-        ctx.meta = (gates, beta_not, hops, causal, prec, path, m8, ms)
+        ctx.meta = (gates, beta_not, hops, causal, prec, path, m8, ms, drop)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
         *ts, lg, y, saved = ctx.saved_tensors
-        gates, beta_not, hops, causal, prec, path, m8, ms = ctx.meta
+        gates, beta_not, hops, causal, prec, path, m8, ms, drop = ctx.meta
         B, N, H, dk = ts[0].shape
         dev = ts[0].device
         dy = dy.contiguous().to(ts[0].dtype).view(B, N, H, dk)
@@ -652,6 +660,7 @@ class _DualPathFn(torch.autograd.Function):
         a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
         a.chain_logit = lg.data_ptr()
         a.y, a.dy = _v4(y), _v4(dy)
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         mk = torch.zeros if hops == 0 else torch.empty          # hops == 0: dv2 is never written
         gs = [mk(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(6)]
         a.dq1, a.dk1, a.dv1, a.dq2, a.dk2, a.dv2 = (_v4(g) for g in gs)
@@ -662,13 +671,14 @@ class _DualPathFn(torch.autograd.Function):
         with _timed("dualpath_bwd"):
             rc = lib.mopk_dualpath_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_dualpath_bwd")
-        return (*gs, dlg.sum().reshape(()), None, None, None, None, None, None, None)
+        return (*gs, dlg.sum().reshape(()), None, None, None, None, None, None, None, None)
 
 
 def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_chain, beta_not, hops,
-                  attn_mask=None, causal=False):
+                  attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
+    drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     return _DualPathFn.apply(q1, k1, v1, q2, k2, v2, chain_logit, (g_and, g_or, g_not, g_chain), beta_not,
-                             int(hops), attn_mask, causal, _prec_for(q1.dtype), _PATH)
+                             int(hops), attn_mask, causal, _prec_for(q1.dtype), _PATH, drop)
 
 
 class _QuartetFn(torch.autograd.Function):

@@ -29,8 +29,9 @@ def _masked_softmax(S, blocked):
     return e / e.sum(-1, keepdims=True)
 
 
-def core_fwd(q1, k1, v1, q2, k2, v2, gates, beta_not, hops, chain_logit, blocked=None):
-    """q*,k*,v*: (B,H,N,dk); blocked: bool array broadcastable to (B,H,N,N) or None."""
+def core_fwd(q1, k1, v1, q2, k2, v2, gates, beta_not, hops, chain_logit, blocked=None, drop=None):
+    """q*,k*,v*: (B,H,N,dk); blocked: bool array broadcastable to (B,H,N,N) or None;
+    drop: None or the attn_drop multiplier keep / (1 - p) per edge on the mixed weights (:222 with the mask made explicit)."""
     dk = q1.shape[-1]
     scale = 1.0 / math.sqrt(dk)
     S1 = np.matmul(q1, np.swapaxes(k1, -1, -2)) * scale          # :200
@@ -57,10 +58,11 @@ def core_fwd(q1, k1, v1, q2, k2, v2, gates, beta_not, hops, chain_logit, blocked
         tr.append(np.matmul(A2, tr[-1]))
     y_chain = np.matmul(A1, tr[-1])                               # :227
     w = _sigmoid(chain_logit)
-    y = np.matmul(P, v1) + w * y_chain                            # :229
+    Pd = P if drop is None else P * drop                          # :222
+    y = np.matmul(Pd, v1) + w * y_chain                           # :229
     cache = dict(q1=q1, k1=k1, v1=v1, q2=q2, k2=k2, v2=v2, S1=S1, S2=S2, A1=A1, A2=A2, T=T,
                  C=C, P=P, tr=tr, y_chain=y_chain, w=w, lse=lse, blocked=blocked, scale=scale,
-                 g=(g_and, g_or, g_not, g_ch), beta=beta_not, hops=hops)
+                 g=(g_and, g_or, g_not, g_ch), beta=beta_not, hops=hops, Pd=Pd, drop=drop)
     return y, cache
 
 
@@ -70,7 +72,9 @@ def core_bwd(dy, c):
     w, hops, blocked = c["w"], c["hops"], c["blocked"]
     dlogit = (dy * c["y_chain"]).sum() * w * (1 - w)
     dP = np.matmul(dy, np.swapaxes(c["v1"], -1, -2))
-    dv1 = np.matmul(np.swapaxes(P, -1, -2), dy)
+    if c.get("drop") is not None:
+        dP = dP * c["drop"]
+    dv1 = np.matmul(np.swapaxes(c.get("Pd", P), -1, -2), dy)
     g = w * dy
     dA1 = np.matmul(g, np.swapaxes(tr[-1], -1, -2))
     gt = np.matmul(np.swapaxes(A1, -1, -2), g)

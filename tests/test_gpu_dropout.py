@@ -170,3 +170,45 @@ def test_edgewise_dropout_matches_the_oracle_under_the_same_mask(save_chain):
         mg.eval()
         e1, e2 = mg(xg), mg(xg)
     assert torch.equal(e1, e2)
+
+
+def test_multihop_dropout_matches_the_oracle_under_the_same_mask():
+    """MultiHopMSA: attn_drop on the mixed weights (:222), transport term undropped (:224-227)"""
+    from mop_amd import ops
+    from oracle import multihop as O
+    torch.manual_seed(9)
+    B, N, H, dk, p, seed, hops = 2, 100, 2, 64, 0.3, 424242424242, 3
+    ts = [torch.randn(B, N, H, dk, device="cuda", dtype=torch.bfloat16).requires_grad_(True) for _ in range(6)]
+    logit = torch.tensor(-0.5, device="cuda", requires_grad=True)
+    w = torch.randn(B, N, H * dk, device="cuda", dtype=torch.bfloat16)
+    y = ops.dualpath_core(*ts, logit, 1.0, 0.3, 0.2, 0.0, 0.5, hops, dropout_p=p, seed=seed)
+    assert ops.LAST_PATH["dualpath_fwd"] == 2
+    y.backward(w)
+    torch.cuda.synchronize()
+    drop = ops.dropout_keep_mask(seed, p, B, H, N).numpy().astype(np.float64) / (1.0 - p)
+    gates = dict(and_=1.0, or_=0.3, not_=0.2, chain=0.0)
+    yr, c = O.core_fwd(*[_bhnd(t) for t in ts], gates, 0.5, hops, float(logit.detach()), None, drop=drop)
+    g = O.core_bwd(w.float().cpu().numpy().reshape(B, N, H, dk).transpose(0, 2, 1, 3).astype(np.float64), c)
+    got = y.detach().float().cpu().numpy().reshape(B, N, H, dk).transpose(0, 2, 1, 3)
+    assert max_abs(got, yr) <= 1e-2 * max(1.0, float(np.abs(yr).max()))
+    for name, t in zip(("dq1", "dk1", "dv1", "dq2", "dk2", "dv2"), ts):
+        assert rel_err(_bhnd(t.grad), g[name]) <= 4e-2, (name, rel_err(_bhnd(t.grad), g[name]))
+
+
+def test_crossview_and_multihop_modules_train_with_attention_dropout():
+    from mop_amd.nn import CrossViewMixerMSA, MultiHopMSA
+    torch.manual_seed(0)
+    x = torch.randn(2, 64, 128, device="cuda", dtype=torch.bfloat16)
+    for m in (MultiHopMSA(128, 2, attn_drop=0.2), CrossViewMixerMSA(128, 2, attn_drop=0.2, use_transpose_cues=False)):
+        m = m.cuda().to(torch.bfloat16).train()
+        xi = x.clone().requires_grad_(True)
+        t1 = m(xi)
+        t1.float().square().sum().backward()
+        with torch.no_grad():
+            t2 = m(x)
+            m.eval()
+            e1, e2 = m(x), m(x)
+        assert torch.equal(e1, e2) and not torch.equal(t1.detach(), t2) and torch.isfinite(xi.grad).all()
+    cues = CrossViewMixerMSA(128, 2, attn_drop=0.2, use_transpose_cues=True, t1=0.3).cuda().to(torch.bfloat16).train()
+    with pytest.raises(NotImplementedError, match="attn_drop"):
+        cues(x)

@@ -97,16 +97,13 @@ def test_unsupported_variants_raise_instead_of_falling_back():
 
 
 def test_attention_dropout_in_training_raises_where_the_kernels_do_not_carry_it():
-    """the reference applies attn_drop to the attention weights (attention_variants.py:45, :153, :222, :552).  The fused SDPA and
-    Quartet kernels and the fused low-rank Edgewise kernels carry it (BaselineMSA, MSA, Whisper's MultiheadSelfAttention,
-    CausalSelfAttention, EdgewiseMSA(gate_mode="lowrank"): tests/test_gpu_dropout.py);
-    the other cores do not, and refuse the configuration instead of silently training a different model."""
-    from mop_amd.nn import CrossViewMixerMSA, EdgewiseMSA, MultiHopMSA
-    x = torch.randn(1, 8, 64)
-    for cls, kw in ((MultiHopMSA, {}), (CrossViewMixerMSA, {}), (EdgewiseMSA, dict(gate_mode="dense"))):
-        m = cls(64, 4, attn_drop=0.1, **kw).train()
-        with pytest.raises(NotImplementedError, match="attn_drop"):
-            m(x)
+    """the reference applies attn_drop to the attention weights (attention_variants.py:45, :153, :222, :552).  The fused kernels carry
+    it (tests/test_gpu_dropout.py); configurations that run the generic path refuse it instead of silently training a different
+    model -- e.g. the dense gate head."""
+    from mop_amd.nn import EdgewiseMSA
+    m = EdgewiseMSA(64, 4, attn_drop=0.1, gate_mode="dense").train()
+    with pytest.raises(NotImplementedError, match="attn_drop"):
+        m(torch.randn(1, 8, 64))
 
 
 def test_dropout_mask_restatement_matches_the_library():
