@@ -336,24 +336,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
     };
-    // uniform-index access to a packed slab inside rolled tile loops
-    auto pk_get = [&](const bf16x8 (&Xp)[NT][2], int t, bf16x8 &lo, bf16x8 &hi) {
-        lo = Xp[0][0]; hi = Xp[0][1];
-        switch (t) {
-#define MOPK_GP(K_) case K_: if (K_ < NT) { lo = Xp[K_ < NT ? K_ : 0][0]; hi = Xp[K_ < NT ? K_ : 0][1]; } break;
-            MOPK_GP(1) MOPK_GP(2) MOPK_GP(3) MOPK_GP(4) MOPK_GP(5) MOPK_GP(6)
-#undef MOPK_GP
-            default: break;
-        }
-    };
-    auto pk_set = [&](bf16x8 (&Xp)[NT][2], int t, bf16x8 lo, bf16x8 hi) {
-        switch (t) {
-#define MOPK_SP(K_) case K_: if (K_ < NT) { Xp[K_ < NT ? K_ : 0][0] = lo; Xp[K_ < NT ? K_ : 0][1] = hi; } break;
-            MOPK_SP(0) MOPK_SP(1) MOPK_SP(2) MOPK_SP(3) MOPK_SP(4) MOPK_SP(5) MOPK_SP(6)
-#undef MOPK_SP
-            default: break;
-        }
-    };
     auto load_rows = [&](bf16x8 (&Bf)[NT][2], const unsigned short *Bm) {      // this lane's row of an exported image ("row slab" order:
         const u32x4 *p = (const u32x4 *)Bm + (size_t)w * 2 * NT * 64 + lane;  //  [wave][2t+s][lane] -> coalesced 1 KiB per fragment)
 #pragma unroll
@@ -416,15 +398,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) out[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, cur[dt], out[dt], 0, 0, 0);
-        }
-    };
-    // AT image of a packed slab with a rolled tile loop (uniform switch picks the registers)
-    auto store_i_packed = [&](unsigned short *dst, const bf16x8 (&Xp)[NT][2]) {
-#pragma nounroll
-        for (int t = 0; t < NT; ++t) {
-            bf16x8 lo, hi;
-            pk_get(Xp, t, lo, hi);
-            store_i_tile(dst, t, lo, hi);
         }
     };
     auto slot_st = [&](int s, const bf16x8 (&Xp)[NT][2]) {
@@ -801,6 +774,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ================= P8: dv0 = P^T dy, dvL = w C->^T dy =================
     {
+        // a packed tile (lane = query, registers = keys) -> rows 32t.. of the AT-format image in R: transposed on the matrix core
+        // (X . I), two 16-byte LDS stores per tile (the 2-byte scatter form costs sixteen)
+        bf16x8 idl8, idh8;
+        identity_frags(idl8, idh8, r, h);
+        auto image_tile = [&](int t, bf16x8 lo, bf16x8 hi) {
+            f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, idl8, zero16(), 0, 0, 0);
+            tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, idh8, tr, 0, 0, 0);
+            bf16x8 tl, th;
+            pack_tile_bf(tl, th, tr);
+            unsigned short *dst = R + (32 * t + r) * LDA + 32 * w + 8 * h;
+            *(bf16x8 *)dst = tl;
+            *(bf16x8 *)(dst + 16) = th;
+        };
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
             f32x16 P = p_tile(t);
@@ -810,17 +796,19 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
             bf16x8 lo, hi;
             pack_tile_bf(lo, hi, P);
-            store_i_tile(R, t, lo, hi);
+            image_tile(t, lo, hi);
         }
         __syncthreads();
         f32x16 g0[DT], gL[DT];
         gemm_rows_glob(g0, R, DYT);                    // dV0e[j in tile w][d]
-        __syncthreads();
-        {
-            bf16x8 Xp[NT][2];
-            slot_ld(S_CF, Xp);
-            pin_slab(Xp);
-            store_i_packed(R, Xp);
+        {   // C-> image: slab tiles requested together, transposed on the matrix core after the readers of the P image are done
+            const u32x4 *p = slot(S_CF);
+            u32x4 buf[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { buf[t][0] = p[(2 * t) * 64]; buf[t][1] = p[(2 * t + 1) * 64]; }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) image_tile(t, as_b8(buf[t][0]), as_b8(buf[t][1]));
         }
         __syncthreads();
         gemm_rows_glob(gL, R, DYT);                    // (C->^T dy)[j][d]
