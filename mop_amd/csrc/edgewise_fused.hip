@@ -35,8 +35,15 @@ namespace mopk {
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
 
-template <int NT, int DK, typename IOT, bool SAVE>
-__global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs a) {
+// device pointers of the dense gate head (MopkEdgewiseExt is a host struct): conv1 (16, C) / (16), conv2 (4, 16) / (4)
+struct FusedDenseW { const float *W1, *b1, *W2, *b2; };
+
+// HEAD: 0 = low-rank gate head (row / col means, rank-r outer products); 1 = dense gate head without the 3x3 convolution
+//       (reference :250-272, :312-318: per edge sigmoid(W2 gelu_tanh(W1 f + b1) + b2) on f = [S_v, S_v^T, Cr, Cl]) evaluated inside
+//       the mix tile loop: the score tiles of both orientations are recomputed per register quarter (40 MFMAs -- the matrix pipe is
+//       idle here), the 16 hidden units of four edges per lane live in registers, C<- comes back from this wave's own export.
+template <int NT, int DK, typename IOT, bool SAVE, int HEAD = 0>
+__global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs a, FusedDenseW dw) {
     using Cfg = FusedCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = Cfg::LDK, KS = Cfg::KS, DT = Cfg::DT, DP = Cfg::DP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -371,6 +378,15 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 }
             }
             if (DK < DP) for (int c = tid; c < (DP - DK) * LDA; c += NT * 64) { VT0[DK * LDA + c] = 0; VTL[DK * LDA + c] = 0; }
+            if constexpr (HEAD == 1) {      // q rows [token][d] in the region the low-rank head uses for its b vectors: A operand of S_v^T
+                const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
+                for (int c = tid; c < NP * CH; c += NT * 64) {
+                    const int j = c / CH, dc = c % CH;
+                    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (j < N) v = load8_bf16<IOT>(qp + (int64_t)j * a.q.sn + dc * 8);
+                    *(bf16x8 *)&bT[j * LDK + dc * 8] = v;
+                }
+            }
             if (tid < NP) { float c = 0.f; for (int ww = 0; ww < NT; ++ww) c += colpart[ww * NP + tid]; c *= invN; cCr[tid] = c;
                             if (SAVE) ((float *)(svb + SL.oMeans))[2 * NP + tid] = c; }
             if (SAVE) {   // softmax constants of every view (still in `cst`, about to be overwritten by rS) and the log-means
@@ -381,7 +397,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             }
             // row / col means of S_v are linear in q, k:  rS_v[i] = Qe_v[i,:].kbar ; cS_v[j] = k[j,:].(sqk_v*qbar)
             // (written over the softmax constants `cst`, which the chains no longer need)
-            {
+            if constexpr (HEAD == 0) {
                 bf16x8 qf[KS];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(qrow + 16 * s + 8 * h); qf[s] = v; }
@@ -425,7 +441,18 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     REFRESH();
     // ---------------- gate vectors                                     :323-326
     const int C = 2 * V + 2;
-    float *Wsm = Cfg::WSM_EXTRA ? wsig + 8 : colpart;   // [2][16][19] gate-head weights (+bias in slot 18); colpart is dead from here on
+    float *Wsm = Cfg::WSM_EXTRA ? wsig + 8 : colpart;   // low-rank: [2][16][19] gate-head weights (+bias in slot 18); dense: W1^T [C][16], b1, W2^T [16][4], b2.  colpart is dead from here on
+    bf16x8 af4[4];                        // low-rank: a[g,k,i] as B fragments: slots [a_hi | a_lo | a_hi | 0]
+    if constexpr (HEAD == 1) {
+        // dense head weights, transposed so that one 16-byte LDS read yields the four values an inner loop needs:
+        //   W1T[c][k] (k = hidden unit) at Wsm[c * 16 + k], b1 at Wsm[18 * 16 + k], W2T[k][m] at Wsm[320 + k * 4 + m], b2 at Wsm[384 + m]
+        for (int c = tid; c < 16 * C; c += NT * 64) Wsm[(c % C) * 16 + c / C] = dw.W1[c];             // W1 is (16, C) row-major
+        for (int c = tid; c < 16; c += NT * 64) Wsm[18 * 16 + c] = dw.b1[c];
+        for (int c = tid; c < 64; c += NT * 64) Wsm[320 + (c % 16) * 4 + c / 16] = dw.W2[c];          // W2 is (4, 16) row-major
+        if (tid < 4) Wsm[384 + tid] = dw.b2[tid];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) af4[g] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    } else {
     for (int c = tid; c < 2 * 4 * R * (C + 1); c += NT * 64) {
         const int side = c / (4 * R * (C + 1)), rem = c % (4 * R * (C + 1)), o = rem / (C + 1), cc = rem % (C + 1);
         const float *Wg = side ? a.Wc : a.Wr, *bg = side ? a.bc : a.br;
@@ -458,7 +485,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
         for (int k = 0; k < 4; ++k) { row[k] = hi[k]; row[4 + k] = hi[k]; row[8 + k] = lo[k]; row[12 + k] = 0; }
     }
-    bf16x8 af4[4];                        // a[g,k,i] as B fragments: slots [a_hi | a_lo | a_hi | 0]
     float av16[4][4];                      // a[g,k] for this lane's query: 16 independent fma chains over the feature channels
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -491,6 +517,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             af4[g][4 + k] = h == 0 ? (short)lo : (short)0;  // h=0: slots 4-7 a_lo ; h=1: slots 12-15 0
         }
     }
+    }
     LDS_BARRIER();                      // bT complete
     FSTAMP();
     REFRESH();
@@ -508,6 +535,24 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     bf16x8 qraw[KS];                      // raw q fragments resident through the mix loop
 #pragma unroll
     for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(qrow + 16 * s + 8 * h); qraw[s] = v; }
+    bf16x8 kraw[HEAD == 1 ? KS : 1];      // dense head: raw k fragments of this lane's token (B operand of the S_v^T tiles)
+    if constexpr (HEAD == 1) {
+        const IOT *krow = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh + (int64_t)qi * a.k.sn;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; if (qok) v = load8_bf16<IOT>(krow + 16 * s + 8 * h); kraw[s] = v; }
+    }
+    // S_v^T tile: element (lane = my token i, register = token j of tile t) = S_v(j, i) = (q_j * sqk_v) . k_i  -- q rows from LDS
+    auto st_tile = [&](const bf16x8 (&ke)[KS], int t) -> f32x16 {
+        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 af[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = *(const bf16x8 *)&(bT + r * LDK + 8 * h)[(32 * t) * LDK + 16 * s];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(af[s]));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], ke[s], acc, 0, 0, 0);
+        return acc;
+    };
     // runtime loop over key tiles (an unrolled one makes hipcc overlap the tiles' live ranges and
     // spill ~1000 VGPRs); the per-tile packed Cr/Smix registers are selected with a uniform switch.
 #pragma nounroll
@@ -550,6 +595,88 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 __builtin_nontemporal_store(f32x4{L[4 * q], L[4 * q + 1], L[4 * q + 2], L[4 * q + 3]} * 1.4426950408889634f, &lp[(4 * t + q) * 64]);
         }
         // Smix = S0 + (G_and - nb G_not) O + G_or L + G_chain Cr, one gate at a time
+        f32x16 G3d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (HEAD == 1) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+            const u4 *cbp = (const u4 *)(svb + SL.oCB + (size_t)w * NT * 8 * 64 * 4) + lane;      // this wave's own C<- export
+            const bf16x8 cbl = __builtin_bit_cast(bf16x8, cbp[(2 * t) * 64]), cbh = __builtin_bit_cast(bf16x8, cbp[(2 * t + 1) * 64]);
+            f32x16 Crv, Clv;                      // log C-> (from the packed fp16 registers) and log C<- of this tile
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                Crv[2 * p] = h2_lo(cw[p]); Crv[2 * p + 1] = h2_hi(cw[p]);
+                Clv[p] = __logf(bf2f((unsigned short)cbl[p]) + EPSC); Clv[8 + p] = __logf(bf2f((unsigned short)cbh[p]) + EPSC);
+            }
+            // rolled over the four register quarters (unrolled, hipcc overlaps them and spills 700 registers); the quarter's registers
+            // are picked with a wave-uniform index into the accumulator vectors (register-indexed moves)
+#pragma nounroll
+            for (int q4 = 0; q4 < 4; ++q4) {                          // registers 4 q4 .. 4 q4 + 3 of the tile: four edges per lane
+                float z1[16][4];
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = bb[kk];
+                }
+                auto accum = [&](int c, const float (&f)[4]) {         // z1 += W1[:, c] (x) f
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const float4 wv = *(const float4 *)&Wsm[c * 16 + 4 * k4];
+                        const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = fmaf(ww[kk], f[e], z1[4 * k4 + kk][e]);
+                    }
+                };
+                {
+                    bf16x8 qe[KS];
+                    for (int v = 0; v < V; ++v) {
+                        scale_qe(qe, qraw, v);
+                        const f32x16 Sv = s_tile(qe, t);
+                        { const float f[4] = {Sv[4 * q4], Sv[4 * q4 + 1], Sv[4 * q4 + 2], Sv[4 * q4 + 3]}; accum(v, f); }
+                        scale_qe(qe, kraw, v);
+                        const f32x16 Tv = st_tile(qe, t);
+                        { const float f[4] = {Tv[4 * q4], Tv[4 * q4 + 1], Tv[4 * q4 + 2], Tv[4 * q4 + 3]}; accum(V + v, f); }
+                    }
+                }
+                { const float f[4] = {Crv[4 * q4], Crv[4 * q4 + 1], Crv[4 * q4 + 2], Crv[4 * q4 + 3]}; accum(2 * V, f); }
+                { const float f[4] = {Clv[4 * q4], Clv[4 * q4 + 1], Clv[4 * q4 + 2], Clv[4 * q4 + 3]}; accum(2 * V + 1, f); }
+                float zz[4][4];
+                {
+                    const float4 bv = *(const float4 *)&Wsm[384];
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zz[m][e] = bb[m];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float4 wv = *(const float4 *)&Wsm[320 + 4 * k];
+                    const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = z1[k][e];                     // gelu_tanh(u) = u * sigmoid(2 sqrt(2/pi) (u + 0.044715 u^3))
+                        const float hv = u * __builtin_amdgcn_rcpf(1.f + __expf(-1.5957691216057308f * (u + 0.044715f * u * u * u)));
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) zz[m][e] = fmaf(ww[m], hv, zz[m][e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int g = 4 * q4 + e;
+                    const float g0 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[0][e])), g1 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[1][e]));
+                    const float g2 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[2][e]));
+                    S0[g] = fmaf(g0, O[g], S0[g]);
+                    S0[g] = fmaf(g1, L[g], S0[g]);
+                    S0[g] = fmaf(-nb * g2, O[g], S0[g]);
+                    G3d[g] = __builtin_amdgcn_rcpf(1.f + __expf(-zz[3][e]));
+                }
+            }
+        } else {
         {
             const f32x16 G = gate_tile(t, 0);
 #pragma unroll
@@ -565,8 +692,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int g = 0; g < 16; ++g) S0[g] = fmaf(-nb * G[g], O[g], S0[g]);
         }
+        }
         {
-            const f32x16 G = gate_tile(t, 3);
+            f32x16 G = G3d;
+            if constexpr (HEAD == 0) G = gate_tile(t, 3);
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 float s0 = fmaf(G[2 * p], h2_lo(cw[p]), S0[2 * p]);
@@ -655,13 +784,17 @@ int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     const int lds = FusedCfg<NT, DK>::lds_bytes(a->V);
     if (lds > 160 * 1024) return MOPK_ERR_UNSUPPORTED;
     const dim3 grid(a->B * a->H), block(NT * 64);
-#define MOPK_LAUNCH(IOT_, SAVE_) do {                                                                             \
-        auto kfn = ew_fused_fwd_kernel<NT, DK, IOT_, SAVE_>;                                                      \
+    const bool dense = a->ext && a->ext->gate_mode == 1;          // dense gate head (no 3x3, no lens): HEAD = 1, always with the full record
+    FusedDenseW dw{nullptr, nullptr, nullptr, nullptr};
+    if (dense) dw = FusedDenseW{a->ext->W1, a->ext->b1, a->ext->W2, a->ext->b2};
+#define MOPK_LAUNCH(IOT_, SAVE_, HEAD_) do {                                                                      \
+        auto kfn = ew_fused_fwd_kernel<NT, DK, IOT_, SAVE_, HEAD_>;                                               \
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a);                                                        \
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, dw);                                                    \
     } while (0)
-    if (a->io_dtype == MOPK_BF16) { if (a->save_for_backward) MOPK_LAUNCH(unsigned short, true); else MOPK_LAUNCH(unsigned short, false); }
-    else { if (a->save_for_backward) MOPK_LAUNCH(float, true); else MOPK_LAUNCH(float, false); }
+    if (dense) { if (a->io_dtype == MOPK_BF16) MOPK_LAUNCH(unsigned short, true, 1); else MOPK_LAUNCH(float, true, 1); }
+    else if (a->io_dtype == MOPK_BF16) { if (a->save_for_backward) MOPK_LAUNCH(unsigned short, true, 0); else MOPK_LAUNCH(unsigned short, false, 0); }
+    else { if (a->save_for_backward) MOPK_LAUNCH(float, true, 0); else MOPK_LAUNCH(float, false, 0); }
 #undef MOPK_LAUNCH
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
@@ -687,7 +820,11 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
     if (a->precision != MOPK_PREC_BF16) return 0;             // fused kernels are the bf16-MFMA path
-    if (a->ext && (a->ext->gate_mode != 0 || a->ext->n_lens > 0)) return 0;   // dense head / lens bank: generic path
+    if (a->ext && a->ext->n_lens > 0) return 0;               // lens banks: generic path
+    if (a->ext && a->ext->gate_mode != 0) {                   // dense gate head: forward only, without the 3x3 convolution, full record
+        if (a->ext->gate_mode != 1 || a->ext->use_k3 || !a->save_for_backward) return 0;
+        if (!a->ext->W1 || !a->ext->b1 || !a->ext->W2 || !a->ext->b2) return 0;
+    }
     if (a->q.sv != 0 || a->k.sv != 0) return 0;               // share_qkv only (per-view K restaging not built)
     if (pick_nt(a->N) == 0) return 0;
     if (a->dk != 16 && a->dk != 32 && a->dk != 64) return 0;

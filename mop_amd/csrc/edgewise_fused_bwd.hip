@@ -1293,6 +1293,7 @@ int ew_fused_bwd_lds_bytes(int nt, int dk, int V) {
 }
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {
     if (!ew_fused_fwd_supported(a)) return 0;
+    if (a->ext && a->ext->gate_mode != 0) return 0;          // the dense head exists as a fused forward only
     if (a->dq.sv != 0 || a->dk_.sv != 0) return 0;
     // the backward reads dy and writes dq / dk / dv with 16-byte vectors, like the forward does q, k, v, y
     const int64_t al = 16 / (a->io_dtype == MOPK_BF16 ? 2 : 4);

@@ -279,7 +279,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
     (unused ones are passed as empty tensors)."""
 
     @staticmethod
-    def forward(ctx, qkv, sqk, vs0, vsL, logit, h0, h1, h2, h3, W3, b3, lens_w, beta_not, V, prec, var):
+    def forward(ctx, qkv, sqk, vs0, vsL, logit, h0, h1, h2, h3, W3, b3, lens_w, beta_not, V, prec, var, wants_grad=True):
         _require_gpu(qkv, "EdgewiseMSA")
         lib = L.lib()
         B, N, Vq, _, H, dk = qkv.shape
@@ -302,9 +302,15 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         a.ext = C.pointer(ext)
         y = torch.empty(B, N, H, dk, dtype=qkv.dtype, device=dev)
         a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
-        LAST_PATH["edgewise_fwd"] = L.PATH_GENERIC
+        # dense head without the 3x3 convolution / lens bank: the fused forward evaluates it inside its mix loop (no backward yet, so
+        # only calls that will not be differentiated take it)
+        if var.dense and not var.use_k3 and not var.lens_dilations and not wants_grad and _PATH != L.PATH_GENERIC:
+            a.path, a.save_for_backward = L.PATH_FUSED, 1
+            if not lib.mopk_edgewise_fused_supported(C.byref(a)):
+                a.path, a.save_for_backward = L.PATH_GENERIC, 0
+        LAST_PATH["edgewise_fwd"] = int(a.path)
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
-        ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
+        ws = _bytes(256 if a.path == L.PATH_FUSED else lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("edgewise_fwd"):
             rc = lib.mopk_edgewise_fwd(C.byref(a), _stream())
@@ -312,6 +318,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         ctx.save_for_backward(qkv, saved, *f.values())
         ctx.keys = list(f.keys())
         ctx.meta = (beta_not, V, prec, var, int(a.r))
+        ctx.fwd_path = int(a.path)
         return y.view(B, N, H * dk)
 
     @staticmethod
@@ -320,6 +327,8 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         qkv, saved, *rest = ctx.saved_tensors
         f = dict(zip(ctx.keys, rest))
         beta_not, V, prec, var, r = ctx.meta
+        if ctx.fwd_path != L.PATH_GENERIC:
+            raise RuntimeError("the fused dense-head forward has no backward; it is only taken for calls that need no gradient")
         B, N, Vq, _, H, dk = qkv.shape
         dev = qkv.device
         dy = dy.contiguous()
@@ -359,7 +368,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
             rc = lib.mopk_edgewise_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_bwd")
         return (dqkv, dsqk.sum(0), dvs0.sum(0), dvsL.sum(0), dlg.sum().reshape(()), g["h0"], g["h1"], g["h2"], g["h3"],
-                g["W3"], g["b3"], g["lens_w"], None, None, None, None)
+                g["W3"], g["b3"], g["lens_w"], None, None, None, None, None)
 
 
 def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float, n_views: int, variant: EdgewiseVariant,
@@ -369,8 +378,11 @@ def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float
     lens_w (L,V,3,3).  qkv as in edgewise_lowrank_core."""
     prec = _prec_for(qkv.dtype) if precision is None else precision
     e = qkv.new_zeros(0, dtype=torch.float32)
+    # decided here: inside Function.forward autograd is already switched off
+    wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                 for t in (qkv, sqk, vs0, vsL, chain_logit, *head, W3, b3, lens_w))
     return _EdgewiseGeneralFn.apply(qkv, sqk, vs0, vsL, chain_logit, *head, e if W3 is None else W3, e if b3 is None else b3,
-                                    e if lens_w is None else lens_w, beta_not, n_views, prec, variant)
+                                    e if lens_w is None else lens_w, beta_not, n_views, prec, variant, wants_grad)
 
 
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,

@@ -434,6 +434,71 @@ def test_variants_vs_oracle_at_full_sequence_length(variant):
     check_grads(grads, g_ref, 1e-3, floor=1e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 197, 384, 6, 5), (3, 50, 128, 2, 3), (1, 8, 64, 4, 2), (2, 129, 64, 1, 4), (1, 224, 128, 4, 8)])
+def test_fused_dense_head_forward_vs_oracle_and_generic(shape):
+    """dense gate head without the 3x3 convolution (attention_variants.py:250-272 minus :253-254, :312-318) evaluated inside the fused
+    forward's mix loop (bf16 score tiles, fp32 MLP): vs the float64 oracle on bf16-rounded inputs, and vs the generic path.  No fused
+    backward exists yet, so the fused kernel is taken under no_grad only and a differentiated call stays on the generic path."""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import EdgewiseMSA
+    B, N, D, H, V = shape
+    torch.manual_seed(N * 7 + V)
+    m = EdgewiseMSA(D, H, n_views=V, share_qkv=True, gate_mode="dense", use_k3=False, gate_init="and")
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("_scale"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif n_.endswith("conv2.bias"):
+                p.copy_(0.7 * torch.randn_like(p))          # the -5 preset leaves every gate ~0
+            elif "conv1" in n_ or "conv2" in n_:
+                p.mul_(1.5)
+        m.chain_value_logit.fill_(-0.5)
+    x = torch.randn(B, N, D)
+    rb = lambda t: torch.as_tensor(t).to(torch.bfloat16).double().numpy()
+    params = {k: rb(v) for k, v in m.state_dict().items()}
+    out, _ = oe.module_fwd(rb(x), params, H, V, True, 0.5)
+    mop_amd.set_precision("bf16")
+    try:
+        mg = m.cuda().to(torch.bfloat16).eval()
+        xg = x.cuda().to(torch.bfloat16)
+        with torch.no_grad():
+            y = mg(xg)
+        assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED
+        ops.set_path("generic")
+        with torch.no_grad():
+            yg = mg(xg)
+        assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_GENERIC
+        ops.set_path("auto")
+        xr = xg.clone().requires_grad_(True)
+        mg(xr).float().sum().backward()                     # a differentiated call: generic forward + backward
+        assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_GENERIC and torch.isfinite(xr.grad).all()
+    finally:
+        ops.set_path("auto")
+        mop_amd.set_precision("auto")
+    scale = max(1.0, float(np.abs(out).max()))
+    assert max_abs(y.float().cpu().numpy(), out) <= 1e-2 * scale, f"fused vs oracle {max_abs(y.float().cpu().numpy(), out):.3e}"
+    assert max_abs(y.float().cpu().numpy(), yg.float().cpu().numpy()) <= 1.5e-2 * scale
+
+
+def test_fused_dense_head_forward_vs_reference_fixture():
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import EdgewiseMSA
+    d, params, _, meta = load_golden("ewx_tiny_dense_v2")
+    m = module_from_golden(EdgewiseMSA, params, dim=int(meta["dim"]), heads=int(meta["heads"]), n_views=int(meta["n_views"]),
+                           share_qkv=bool(meta["share_qkv"]), gate_mode="dense", use_k3=False)
+    mop_amd.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            y = m(torch.from_numpy(d["x"]).cuda())
+        assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED
+    finally:
+        mop_amd.set_precision("auto")
+    assert max_abs(y.cpu().numpy(), d["y"]) <= TOL_BF16
+
+
 def test_fused_lowrank_batch_of_three_at_full_size_vs_oracle():
     """B = 3 images at the north-star layer shape (N = 197, D = 384, 6 heads, 5 views, r = 4), fused bf16 kernels vs the float64 oracle:
     the reference fixture at this shape is B = 1, so batch striding of every launch (saved records, hand-off regions, partials) is

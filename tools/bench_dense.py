@@ -1,20 +1,42 @@
+"""dev tool (GPU box): EdgewiseMSA layer at the bench shape (B=256, N=197, D=384, H=6, V=5, bf16) with the low-rank head, the dense
+head and dense + k3: training step (fwd+bwd) and inference forward; the dense head without k3 runs its inference forward on the
+fused kernel (set_path('generic') shows the generic one)."""
 import sys, time, torch
 sys.path.insert(0, ".")
+from mop_amd import ops
 from mop_amd.nn import EdgewiseMSA
+
+
+def timed(fn, n=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.time() - t) / n * 1e3
+
+
 def run(gate_mode, use_k3, B=256):
     torch.manual_seed(0)
     m = EdgewiseMSA(384, 6, n_views=5, share_qkv=True, gate_mode=gate_mode, gate_rank=4, use_k3=use_k3).cuda().to(torch.bfloat16)
     x = torch.randn(B, 197, 384, device="cuda", dtype=torch.bfloat16, requires_grad=True)
     w = torch.randn_like(x)
-    for _ in range(2):
-        m(x).backward(w)
-    torch.cuda.synchronize()
-    t = time.time()
-    n = 3
-    for _ in range(n):
-        m(x).backward(w)
-    torch.cuda.synchronize()
-    print(gate_mode, "k3" if use_k3 else "", f"B={B}: {(time.time()-t)/n*1e3:.1f} ms/step, peak mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB", flush=True)
+    step = timed(lambda: m(x).backward(w), 3)
+    def infer():
+        with torch.no_grad():
+            m(x)
+    fwd = timed(infer)
+    path = ops.LAST_PATH["edgewise_fwd"]
+    line = f"{gate_mode:8s} {'k3' if use_k3 else '  '} B={B}: train step {step:7.1f} ms | inference fwd {fwd:6.2f} ms (path {path})"
+    if gate_mode == "dense" and not use_k3:
+        ops.set_path("generic")
+        line += f" | generic inference fwd {timed(infer):6.2f} ms"
+        ops.set_path("auto")
+    print(line + f" | peak mem {torch.cuda.max_memory_allocated() / 1e9:.1f} GB", flush=True)
+
+
 run("lowrank", False)
 run("dense", False)
 run("dense", True)
