@@ -44,7 +44,7 @@ static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
         if (dense && (!x->W1 || !x->b1 || !x->W2 || !x->b2 || (x->use_k3 && (!x->W3 || !x->b3)))) return MOPK_ERR_BAD_ARG;
         if (dense && bwd && (!x->dW1 || !x->db1 || !x->dW2 || !x->db2 || (x->use_k3 && (!x->dW3 || !x->db3)))) return MOPK_ERR_BAD_ARG;
         // lens banks, the 3x3 convolution and every dense-head backward: generic path only (the fused forward takes the plain dense head)
-        if (a->path == MOPK_PATH_FUSED && (x->n_lens > 0 || (dense && (x->use_k3 || bwd)))) return MOPK_ERR_UNSUPPORTED;
+        if (a->path == MOPK_PATH_FUSED && (x->n_lens > 0 || (dense && x->use_k3))) return MOPK_ERR_UNSUPPORTED;
     }
     if (!a->q.ptr || !a->k.ptr || !a->v0.ptr || !a->vL.ptr || !a->sqk || !a->vs0 || !a->vsL || !a->chain_logit || !a->saved ||
         !a->workspace)

@@ -20,7 +20,10 @@ struct BwdWs {
 enum { S_CF = 0, S_CB, S_SM, S_L, X_C3, X_DIR };   // X_DIR .. X_DIR+V-1 (direct score gradients per view), X_DR(V)+v: D_v of the -> chain, X_DL(V)+m: D'_m of the <- chain
 __host__ __device__ constexpr int X_DR(int V) { return X_DIR + V; }
 __host__ __device__ constexpr int X_DL(int V) { return X_DIR + 2 * V; }
-__host__ __device__ constexpr int X_COUNT(int V) { return 1 + 3 * V; }      // slabs in the hand-off region (ids X_C3 ..)
+// dense gate head only: X_DT(V)+v = gradient of the S_v^T feature channel (launch C adds it transposed), X_CL(V) = gradient of log C<-
+__host__ __device__ constexpr int X_DT(int V) { return X_DIR + 3 * V; }
+__host__ __device__ constexpr int X_CL(int V) { return X_DIR + 4 * V; }
+__host__ __device__ constexpr int X_COUNT(int V, bool dense = false) { return dense ? 2 + 4 * V : 1 + 3 * V; }      // slabs in the hand-off region (ids X_C3 ..)
 
 template <int NT, int DK>
 struct BwdCfg {
@@ -30,7 +33,7 @@ struct BwdCfg {
     static constexpr size_t SLOT = (size_t)NT * 8 * 64 * 4;                // one packed slab of one wave
     static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
     // base: nwg per-workgroup scratch regions, then nbh hand-off regions
-    static BwdWs carve(void *base, int V, int nwg, int nbh) {
+    static BwdWs carve(void *base, int V, int nwg, int nbh, bool dense = false) {
         BwdWs w{};
         size_t o = 0;
         w.base = (unsigned char *)base;
@@ -45,14 +48,14 @@ struct BwdCfg {
         w.stride = a256(o);
         w.xbase = w.base + w.stride * (size_t)nwg;
         size_t x = 0;
-        w.xSlots = x; x += a256((size_t)X_COUNT(V) * NT * SLOT);
+        w.xSlots = x; x += a256((size_t)X_COUNT(V, dense) * NT * SLOT);
         w.xDmean = x; x += a256((size_t)(2 * V + 4) * NP * 4);
         w.xstride = a256(x);
         (void)nbh;
         return w;
     }
-    static size_t total_bytes(int V, int nwg, int nbh) {
-        const BwdWs w = carve(nullptr, V, nwg, nbh);
+    static size_t total_bytes(int V, int nwg, int nbh, bool dense = false) {
+        const BwdWs w = carve(nullptr, V, nwg, nbh, dense);
         return w.stride * (size_t)nwg + w.xstride * (size_t)nbh;
     }
     // LDS: R region | Ksm | floats

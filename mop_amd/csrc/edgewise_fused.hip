@@ -35,9 +35,6 @@ namespace mopk {
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
 
-// device pointers of the dense gate head (MopkEdgewiseExt is a host struct): conv1 (16, C) / (16), conv2 (4, 16) / (4)
-struct FusedDenseW { const float *W1, *b1, *W2, *b2; };
-
 // HEAD: 0 = low-rank gate head (row / col means, rank-r outer products); 1 = dense gate head without the 3x3 convolution
 //       (reference :250-272, :312-318: per edge sigmoid(W2 gelu_tanh(W1 f + b1) + b2) on f = [S_v, S_v^T, Cr, Cl]) evaluated inside
 //       the mix tile loop: the score tiles of both orientations are recomputed per register quarter (40 MFMAs -- the matrix pipe is

@@ -22,8 +22,10 @@
 
 namespace mopk {
 
-template <int NT, int DK, typename IOT, int PH>
-__global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W) {
+// HEAD: 0 = low-rank gate head, 1 = dense gate head without the 3x3 convolution (launch A: per-edge MLP backward; launch B: log C<-
+//       gradient slab in the <- chain's seed; launch C: the S_v^T feature gradients added transposed)
+template <int NT, int DK, typename IOT, int PH, int HEAD = 0>
+__global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W, FusedDenseW dw) {
     using Cfg = BwdCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = DK + 8, KS = DK / 16, DT = Cfg::DT, DP = Cfg::DP;
     constexpr int NTH = NT * 64;
@@ -447,6 +449,41 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     __syncthreads();
     STAMP();
     REFRESH();
+    // ================= P4: mix state: Smix / L slabs and the final softmax row statistics come from the forward =================
+    const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
+    bf16x8 dyf[KS];
+    make_frag(dyf, dyrow, nullptr);
+    float mxrow, invl, delta;
+    {
+        // delta_i = sum_j P_ij dP_ij = dy_i . (P v0)_i with the forward's fp32 y_base = P v0
+        const float *rw = (const float *)(svb + SL.oRow), *yb = (const float *)(svb + SL.oYb);
+        mxrow = rw[qi]; invl = rw[NP + qi];
+        float d = 0.f;
+        if (qok) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float4 c0 = *(const float4 *)&yb[(size_t)qi * DK + 16 * s + 8 * h], c1 = *(const float4 *)&yb[(size_t)qi * DK + 16 * s + 8 * h + 4];
+                const float yc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d = fmaf(bf2f((unsigned short)dyf[s][e]), yc[e], d);
+            }
+        }
+        delta = d + __shfl_xor(d, 32, 64);
+    }
+    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
+    const uint32_t rowh = fa_drop_row(drop, bh, qi);
+    auto p_tile = [&](int t) -> f32x16 {      // P tile from the parked Smix
+        const u32x4 *p = slot(S_SM);
+        f32x16 x = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), __builtin_nontemporal_load(&p[(2 * t + 1) * 64]));
+#pragma unroll
+        for (int g = 0; g < 16; ++g) x[g] = __expf(x[g] - mxrow) * invl;
+        return x;
+    };
+    STAMP();
+    REFRESH();
+    STAMP();
+    REFRESH();
+    if constexpr (HEAD == 0) {
     // ================= P3: gate vectors =================
     // gate-head weights -> LDS (row side [16][19], col side [16][19]; slot 18 = bias); R's tail is free from here to P7
     for (int c = tid; c < 2 * 4 * RK * (C + 1); c += NTH) {
@@ -524,8 +561,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     __syncthreads();
     STAMP();
     REFRESH();
-    // ================= P4: mix state: Smix / L slabs and the final softmax row statistics come from the forward =================
-    const float nb = a.beta_not / (float)(V > 1 ? V - 1 : 1);
     auto gate_tile = [&](int t, int g4) -> f32x16 {
         const bf16x8 bfrag = *(const bf16x8 *)&bT[(g4 * NP + 32 * t + r) * BTS + 8 * h];
         f32x16 z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfrag, af4[g4], zero16(), 0, 0, 0);
@@ -533,38 +568,6 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         for (int g = 0; g < 16; ++g) z[g] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z[g]));
         return z;
     };
-    bf16x8 dyf[KS];
-    make_frag(dyf, dyrow, nullptr);
-    float mxrow, invl, delta;
-    {
-        // delta_i = sum_j P_ij dP_ij = dy_i . (P v0)_i with the forward's fp32 y_base = P v0
-        const float *rw = (const float *)(svb + SL.oRow), *yb = (const float *)(svb + SL.oYb);
-        mxrow = rw[qi]; invl = rw[NP + qi];
-        float d = 0.f;
-        if (qok) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const float4 c0 = *(const float4 *)&yb[(size_t)qi * DK + 16 * s + 8 * h], c1 = *(const float4 *)&yb[(size_t)qi * DK + 16 * s + 8 * h + 4];
-                const float yc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) d = fmaf(bf2f((unsigned short)dyf[s][e]), yc[e], d);
-            }
-        }
-        delta = d + __shfl_xor(d, 32, 64);
-    }
-    const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);
-    const uint32_t rowh = fa_drop_row(drop, bh, qi);
-    auto p_tile = [&](int t) -> f32x16 {      // P tile from the parked Smix
-        const u32x4 *p = slot(S_SM);
-        f32x16 x = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), __builtin_nontemporal_load(&p[(2 * t + 1) * 64]));
-#pragma unroll
-        for (int g = 0; g < 16; ++g) x[g] = __expf(x[g] - mxrow) * invl;
-        return x;
-    };
-    STAMP();
-    REFRESH();
-    STAMP();
-    REFRESH();
     // ================= P6: mix backward =================
     f32x16 daacc = zero16();
 #pragma nounroll
@@ -770,6 +773,259 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         }
         __syncthreads();
     }
+    } else {
+    // ================= dense gate head (HEAD == 1; reference :250-272 minus the 3x3, :312-318) =================
+    // Per register quarter of every tile (four edges per lane): features f = [S_v, S_v^T, Cr, Cl] recomputed on the matrix core, MLP
+    // forward (gates), mix backward dG_g = dSmix * term_g, MLP backward -> dz2, dz1, df.  df joins the direct score gradients (S_v
+    // channels: DIR_v; S_v^T channels: their own slabs, added transposed by launch C), C3 (Cr) and a new slab (Cl, seeds the <- chain in
+    // launch B).  Weight gradients: per hidden unit the 16 per-lane partial sums [dW1[k][:], db1[k]] are reduced over the wave with a
+    // halving butterfly (17 shuffles per row instead of 96) and accumulated per wave in LDS.
+    {
+        unsigned short *Qsm = R;                                    // q rows [token][d]: A operand of the S_v^T tiles
+        float *wacc = (float *)(R + NP * LDK);                      // [NT][WACC] weight-gradient sums of this (b,h), per wave
+        constexpr int WACC = 16 * 16 + 16 * 4 + 4;                  // dW1 rows [k][16 slots: c < C, slot 15 = db1] | dW2^T [k][m] | db2[m]
+        {
+            const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
+            constexpr int CH = DK / 8;
+            for (int c = tid; c < NP * CH; c += NTH) {
+                const int j = c / CH, dc = c % CH;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (j < N) v = load8_bf16<IOT>(qp + (int64_t)j * a.q.sn + dc * 8);
+                *(bf16x8 *)&Qsm[j * LDK + dc * 8] = v;
+            }
+            // weights transposed as in the forward: W1T[c][k] at Wsm[c * 16 + k], b1 at Wsm[288 + k], W2T[k][m] at Wsm[320 + 4 k + m], b2 at Wsm[384 + m]
+            for (int c = tid; c < 16 * C; c += NTH) Wsm[(c % C) * 16 + c / C] = dw.W1[c];
+            for (int c = tid; c < 16; c += NTH) Wsm[18 * 16 + c] = dw.b1[c];
+            for (int c = tid; c < 64; c += NTH) Wsm[320 + (c % 16) * 4 + c / 16] = dw.W2[c];
+            if (tid < 4) Wsm[384 + tid] = dw.b2[tid];
+            for (int c = tid; c < NT * WACC; c += NTH) wacc[c] = 0.f;
+        }
+        __syncthreads();
+        float *wme = wacc + w * WACC;
+        auto st_tile = [&](const bf16x8 (&ke)[KS], int t) -> f32x16 {      // S_v^T tile: element (lane = my token i, register = token j) = S_v(j, i)
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 af = *(const bf16x8 *)&(Qsm + r * LDK + 8 * h)[(32 * t) * LDK + 16 * s];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ke[s], acc, 0, 0, 0);
+            }
+            return acc;
+        };
+        // sum over the 64 lanes of sixteen per-lane values: after four halving exchanges lane l holds the sum (over its 16-lane row) of
+        // value idx(l) = 8 b0 + 4 b1 + 2 b2 + b3 (b_i = bit i of l), two more exchanges add the four rows
+        auto reduce16 = [&](const float (&v)[16]) -> float {
+            float a8[8], a4[4], a2[2];
+            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = (b0 ? v[8 + i] : v[i]) + __shfl_xor(b0 ? v[i] : v[8 + i], 1, 64);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a4[i] = (b1 ? a8[4 + i] : a8[i]) + __shfl_xor(b1 ? a8[i] : a8[4 + i], 2, 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a2[i] = (b2 ? a4[2 + i] : a4[i]) + __shfl_xor(b2 ? a4[i] : a4[2 + i], 4, 64);
+            float s = (b3 ? a2[1] : a2[0]) + __shfl_xor(b3 ? a2[0] : a2[1], 8, 64);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            return s;
+        };
+        const int ridx = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);   // slot this lane ends up with
+        const IOT *krow = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh + (int64_t)qi * a.k.sn;
+#pragma nounroll
+        for (int t = 0; t < NT; ++t) {
+            bf16x8 qraw_t[KS], kraw_t[KS], dyf_t[KS];
+            make_frag(qraw_t, qrow, nullptr);
+            make_frag(kraw_t, krow, nullptr);
+            make_frag(dyf_t, dyrow, nullptr);
+            const f32x16 dPt = g_tile(V0s, dyf_t, t);              // dP = dy v0^T for the whole tile; quarters index into it
+#pragma nounroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int hi8 = q4 >> 1, lo2 = q4 & 1;             // this quarter = dwords 2 lo2, 2 lo2 + 1 of the (lo | hi) 16-byte half of a packed tile
+                auto piece = [&](const u32x4 *p) -> uint2 { return ((const uint2 *)&p[(2 * t + hi8) * 64])[lo2]; };
+                auto put = [&](u32x4 *p, float x0, float x1, float x2, float x3) {
+                    ((uint2 *)&p[(2 * t + hi8) * 64])[lo2] = make_uint2(pack_bf16(x0, x1), pack_bf16(x2, x3));
+                };
+                float dSq[4], Lq[4], Crq[4], Clq[4];
+                {
+                    const uint2 sm = piece(slot(S_SM)), cf = piece(slot(S_CF)), cb = piece(slot(S_CB));
+                    const f32x4 l4 = ((const f32x4 *)(svb + SL.oL + (size_t)w * 2 * Cfg::SLOT) + lane)[(4 * t + q4) * 64];
+                    const float smx[4] = {h2_lo(sm.x), h2_hi(sm.x), h2_lo(sm.y), h2_hi(sm.y)};
+                    const unsigned int cfw[2] = {cf.x, cf.y}, cbw[2] = {cb.x, cb.y};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = 32 * t + tile_row(4 * q4 + e, h);
+                        float dp = dPt[4 * q4 + e];
+                        if (drop.thresh) dp = fa_drop_keep(drop, rowh, j) ? dp * drop.inv_keep : 0.f;
+                        const float P = __expf(smx[e] - mxrow) * invl;
+                        dSq[e] = keep_if(j < N, P * (dp - delta));
+                        Lq[e] = l4[e] * 0.6931471805599453f;
+                        Crq[e] = __logf(bf2f((unsigned short)(cfw[e >> 1] >> (16 * (e & 1)))) + EPSC);
+                        Clq[e] = __logf(bf2f((unsigned short)(cbw[e >> 1] >> (16 * (e & 1)))) + EPSC);
+                    }
+                }
+                // ---- features and first layer: z1[k][e] = b1[k] + sum_c W1[k][c] f_c[e]
+                f32x16 F[4];                                        // F[e][c]: channel c of edge e (c < C <= 14; slots C.. stay 0)
+                float z1[16][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) F[e] = zero16();
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = bb[kk];
+                }
+                auto accum = [&](int c, const float (&f)[4]) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) F[e][c] = f[e];
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
+                        const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = fmaf(ww[kk], f[e], z1[4 * k4 + kk][e]);
+                    }
+                };
+                float Oq[4] = {0.f, 0.f, 0.f, 0.f}, S0q[4];
+                {
+                    bf16x8 qe[KS];
+                    for (int v = 0; v < V; ++v) {
+                        scale_frag(qe, qraw_t, sqk + v * DK);
+                        const f32x16 Sv = s_tile(qe, t);
+                        const float fs4[4] = {Sv[4 * q4], Sv[4 * q4 + 1], Sv[4 * q4 + 2], Sv[4 * q4 + 3]};
+                        accum(v, fs4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { if (v == 0) S0q[e] = fs4[e]; else Oq[e] += fs4[e]; }
+                        scale_frag(qe, kraw_t, sqk + v * DK);
+                        const f32x16 Tv = st_tile(qe, t);
+                        const float ft4[4] = {Tv[4 * q4], Tv[4 * q4 + 1], Tv[4 * q4 + 2], Tv[4 * q4 + 3]};
+                        accum(V + v, ft4);
+                    }
+                }
+                accum(2 * V, Crq);
+                accum(2 * V + 1, Clq);
+                // ---- second layer and gates
+                float zz[4][4];
+                {
+                    const float4 bv = *(const float4 *)&Wsm[384];
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) zz[m][e] = bb[m];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
+                    const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = z1[k][e];
+                        const float hv = u * __builtin_amdgcn_rcpf(1.f + __expf(-1.5957691216057308f * (u + 0.044715f * u * u * u)));
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) zz[m][e] = fmaf(ww[m], hv, zz[m][e]);
+                    }
+                }
+                float G[4][4], dzz[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float term[4] = {Oq[e], Lq[e], -nb * Oq[e], Crq[e]};    // d Smix / d G_g: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        G[m][e] = __builtin_amdgcn_rcpf(1.f + __expf(-zz[m][e]));
+                        dzz[m][e] = dSq[e] * term[m] * G[m][e] * (1.f - G[m][e]);
+                    }
+                }
+                // ---- db2, then per hidden unit: h, gelu', dh, dz1 (in place of z1), dW2^T row, dW1 row
+                {
+                    float pb[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) pb[m] = wave_sum((dzz[m][0] + dzz[m][1]) + (dzz[m][2] + dzz[m][3]));
+                    if (lane < 4) wme[16 * 16 + 16 * 4 + lane] += lane == 0 ? pb[0] : lane == 1 ? pb[1] : lane == 2 ? pb[2] : pb[3];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
+                    const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+                    float pw2[4] = {0.f, 0.f, 0.f, 0.f}, row[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) row[c] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = z1[k][e];
+                        const float arg = 1.5957691216057308f * (u + 0.044715f * u * u * u);
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-arg));
+                        const float hv = u * sg;
+                        const float gp = sg + hv * (1.f - sg) * 1.5957691216057308f * (1.f + 0.134145f * u * u);     // d gelu_tanh / du
+                        float dh = 0.f;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) { dh = fmaf(ww[m], dzz[m][e], dh); pw2[m] = fmaf(dzz[m][e], hv, pw2[m]); }
+                        const float d1 = dh * gp;
+                        z1[k][e] = d1;                               // dz1
+#pragma unroll
+                        for (int c = 0; c < 15; ++c) row[c] = fmaf(d1, F[e][c], row[c]);
+                        row[15] += d1;                               // db1
+                    }
+                    const float rs = reduce16(row);
+                    if ((lane >> 4) == 0) wme[16 * k + ridx] += rs;
+                    {   // dW2^T row k: four values; two halving steps, then four plain ones
+                        const bool b0 = lane & 1, b1 = lane & 2;
+                        float a2[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) a2[i] = (b0 ? pw2[2 + i] : pw2[i]) + __shfl_xor(b0 ? pw2[i] : pw2[2 + i], 1, 64);
+                        float s = (b1 ? a2[1] : a2[0]) + __shfl_xor(b1 ? a2[0] : a2[1], 2, 64);
+                        s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                        if (lane < 4) wme[16 * 16 + 4 * k + (((lane & 1) << 1) | ((lane & 2) >> 1))] += s;
+                    }
+                }
+                // ---- df_c = sum_k W1[k][c] dz1[k]  ->  hand-off slabs
+                float g1q[4], gAq[4], lseq[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { g1q[e] = G[1][e]; gAq[e] = fmaf(-nb, G[2][e], G[0][e]); lseq[e] = Lq[e] + S0q[e]; }
+                for (int c = 0; c < C; ++c) {
+                    float df[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
+                        const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) df[e] = fmaf(ww[kk], z1[4 * k4 + kk][e], df[e]);
+                    }
+                    if (c < V) {                                      // S_v channel: direct score gradient dSmix * coef_v + df
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float pi = __expf(F[e][c] - lseq[e]);
+                            const float coef = c == 0 ? (1.f - g1q[e]) + g1q[e] * pi : fmaf(g1q[e], pi, gAq[e]);
+                            o[e] = fmaf(dSq[e], coef, df[e]);
+                        }
+                        put(slot(X_DIR + c), o[0], o[1], o[2], o[3]);
+                    } else if (c < 2 * V) {                           // S_v^T channel: gradient of S_v(j, i), added transposed by launch C
+                        put(slot(X_DT(V) + (c - V)), df[0], df[1], df[2], df[3]);
+                    } else if (c == 2 * V) {                          // Cr: joins the chain-gate term G_chain dSmix
+                        put(slot(X_C3), fmaf(dSq[0], G[3][0], df[0]), fmaf(dSq[1], G[3][1], df[1]), fmaf(dSq[2], G[3][2], df[2]), fmaf(dSq[3], G[3][3], df[3]));
+                    } else {                                          // Cl: seeds the <- D-chain (launch B)
+                        put(slot(X_CL(V)), df[0], df[1], df[2], df[3]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // weight-gradient partials of this workgroup: waves summed in a fixed order, accumulated over the (b,h) it processes
+        for (int c = tid; c < WACC; c += NTH) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NT; ++ww) s += wacc[ww * WACC + c];
+            dwp[c] = first_pass ? s : dwp[c] + s;
+        }
+        for (int c = tid; c < (2 * V + 4) * NP; c += NTH) xdmean[c] = 0.f;      // the dense head has no mean features
+        __syncthreads();
+    }
+    }
     STAMP();
     REFRESH();
     // ================= P8: dv0 = P^T dy, dvL = w C->^T dy =================
@@ -884,11 +1140,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const f32x16 cb = unpack_tile_bf(Xp[t][0], Xp[t][1]);
+                f32x16 dcl = zero16();                 // dense head: per-edge gradient of the log C<- feature (launch A)
+                if constexpr (HEAD == 1) { const u32x4 *pc = slot(X_CL(V)); dcl = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64])); }
                 f32x16 d;
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const int j = 32 * t + tile_row(g, h);
-                    d[g] = keep_if(j < N && qok, (drl + dmean[(2 * V + 3) * NP + j]) * __builtin_amdgcn_rcpf(cb[g] + EPSC));
+                    d[g] = keep_if(j < N && qok, (dcl[g] + drl + dmean[(2 * V + 3) * NP + j]) * __builtin_amdgcn_rcpf(cb[g] + EPSC));
                 }
                 pack_tile_bf(Dp[t][0], Dp[t][1], d);
             }
@@ -1065,7 +1323,18 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         }
                     }
                     const f32x16 A = a_tile(qe, t, cv);
-                    const f32x16 dir = unpack_tile_bf(as_b8(d0), as_b8(d1));
+                    f32x16 dir = unpack_tile_bf(as_b8(d0), as_b8(d1));
+                    if constexpr (HEAD == 1) {
+                        // dense head: the gradient of the S_v^T feature channel at edge (j, i) belongs to dS_v(i, j).  Launch A left it in
+                        // the slab of the wave that owns query block t, at its key tile w: that tile, transposed on the matrix core
+                        // (X . I: lane = my query, registers = keys of tile t), is added here
+                        const u32x4 *pt = (const u32x4 *)(xf + W.xSlots + ((size_t)(X_DT(V) + v - X_C3) * NT + t) * Cfg::SLOT) + lane;
+                        bf16x8 idl8, idh8;
+                        identity_frags(idl8, idh8, r, h);
+                        f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(pt[(2 * w) * 64]), idl8, zero16(), 0, 0, 0);
+                        tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_b8(pt[(2 * w + 1) * 64]), idh8, tr, 0, 0, 0);
+                        dir += tr;
+                    }
                     const f32x16 dA = unpack_tile_bf(dl_, dh_);
                     f32x16 dS;
 #pragma unroll
@@ -1196,8 +1465,9 @@ static int bwd_grid(const MopkEdgewiseArgs *a, int items_per_bh) {       // one 
 static size_t a256h(size_t x) { return (x + 255) & ~(size_t)255; }
 // workspace = [per-workgroup scratch x grid | per-(b,h) hand-off x B*H | (save_for_backward == 0 only) full `saved` record + y scratch
 // for the forward re-run in export mode]
+static bool bwd_dense(const MopkEdgewiseArgs *a) { return a->ext && a->ext->gate_mode == 1; }
 static size_t bwd_core_bytes(const MopkEdgewiseArgs *a) {
-    return a256h(BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::total_bytes(a->V, bwd_grid(a, 2), a->B * a->H));   // scratch for the widest grid (PH_B)
+    return a256h(BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::total_bytes(a->V, bwd_grid(a, 2), a->B * a->H, bwd_dense(a)));   // scratch for the widest grid (PH_B)
 }
 static size_t bwd_full_saved_bytes(const MopkEdgewiseArgs *a) {
     return a256h(fused_saved_layout<MOPK_INST_NT, MOPK_INST_DK>(a->N, a->V, true).stride * (size_t)a->B * a->H + 256);
@@ -1208,6 +1478,7 @@ size_t MOPK_CAT(ew_fused_bwd_ws_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkE
     return n;
 }
 void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st);
+void ew_fused_dense_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st);
 int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a, hipStream_t st);
 int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewiseArgs *a_in, hipStream_t st) {
     constexpr int NT = MOPK_INST_NT, DK = MOPK_INST_DK;
@@ -1230,13 +1501,17 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     }
     const MopkEdgewiseArgs *a = &args;
     const int nwgA = bwd_grid(a, 1), nwgB = bwd_grid(a, 2);
-    const BwdWs W = Cfg::carve(a->workspace, a->V, nwgB, a->B * a->H);     // nwgB >= nwgA
+    const bool dense = bwd_dense(a);
+    const BwdWs W = Cfg::carve(a->workspace, a->V, nwgB, a->B * a->H, dense);     // nwgB >= nwgA
+    FusedDenseW dw{nullptr, nullptr, nullptr, nullptr};
+    if (dense) dw = FusedDenseW{a->ext->W1, a->ext->b1, a->ext->W2, a->ext->b2};
     const dim3 block(NT * 64);
-#define MOPK_LAUNCH(IOT_, PH_, GRID_) do {                                                                        \
-        auto kfn = ew_fused_bwd_kernel<NT, DK, IOT_, PH_>;                                                        \
+#define MOPK_LAUNCH_H(IOT_, PH_, GRID_, HEAD_) do {                                                               \
+        auto kfn = ew_fused_bwd_kernel<NT, DK, IOT_, PH_, HEAD_>;                                                 \
         if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
-        hipLaunchKernelGGL(kfn, dim3(GRID_), block, lds, st, *a, W);                                              \
+        hipLaunchKernelGGL(kfn, dim3(GRID_), block, lds, st, *a, W, dw);                                          \
     } while (0)
+#define MOPK_LAUNCH(IOT_, PH_, GRID_) do { if (dense) MOPK_LAUNCH_H(IOT_, PH_, GRID_, 1); else MOPK_LAUNCH_H(IOT_, PH_, GRID_, 0); } while (0)
     if (a->io_dtype == MOPK_BF16) MOPK_LAUNCH(unsigned short, PH_A, nwgA); else MOPK_LAUNCH(float, PH_A, nwgA);
     MOPK_CHECK_LAUNCH();
     {   // launch B: the two D-chains
@@ -1244,8 +1519,9 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     }
     if (a->io_dtype == MOPK_BF16) MOPK_LAUNCH(unsigned short, PH_C, nwgA); else MOPK_LAUNCH(float, PH_C, nwgA);
 #undef MOPK_LAUNCH
+#undef MOPK_LAUNCH_H
     MOPK_CHECK_LAUNCH();
-    ew_fused_dw_reduce(a, W, nwgA, st);
+    if (dense) ew_fused_dense_dw_reduce(a, W, nwgA, st); else ew_fused_dw_reduce(a, W, nwgA, st);
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
 }
@@ -1271,6 +1547,25 @@ void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipS
     const int nout = 2 * 4 * a->r * (2 * a->V + 3);
     hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3(nout), dim3(256), 0, st, *a, W, nwg);
 }
+// dense head: per-workgroup partials [16 rows x 16 slots (dW1[k][c < C], slot 15 = db1[k]) | dW2^T [k][m] | db2[m]] -> conv1 / conv2 gradients
+struct DenseGradOut { float *dW1, *db1, *dW2, *db2; };
+__global__ void ew_fused_dense_dw_reduce_kernel(BwdWs W, int nwg, int C, DenseGradOut o) {
+    __shared__ float red[256];
+    const int idx = blockIdx.x;                       // 0 .. 323
+    float s = 0.f;
+    for (int g = threadIdx.x; g < nwg; g += 256) s += ((const float *)(W.base + (size_t)g * W.stride + W.oDW))[idx];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+    if (threadIdx.x != 0) return;
+    s = red[0];
+    if (idx < 256) { const int k = idx / 16, c = idx % 16; if (c < C) o.dW1[k * C + c] = s; else if (c == 15) o.db1[k] = s; }
+    else if (idx < 320) { const int k = (idx - 256) / 4, m = (idx - 256) % 4; o.dW2[m * 16 + k] = s; }
+    else o.db2[idx - 320] = s;
+}
+void ew_fused_dense_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st) {
+    const DenseGradOut o{a->ext->dW1, a->ext->db1, a->ext->dW2, a->ext->db2};
+    hipLaunchKernelGGL(ew_fused_dense_dw_reduce_kernel, dim3(324), dim3(256), 0, st, W, nwg, 2 * a->V + 2, o);
+}
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 #define MOPK_DECL(NT_, DK_) int ew_fused_bwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st); \
                             size_t ew_fused_bwd_ws_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a);
@@ -1293,7 +1588,9 @@ int ew_fused_bwd_lds_bytes(int nt, int dk, int V) {
 }
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {
     if (!ew_fused_fwd_supported(a)) return 0;
-    if (a->ext && a->ext->gate_mode != 0) return 0;          // the dense head exists as a fused forward only
+    if (a->ext && a->ext->gate_mode != 0) {                   // dense head (no 3x3): one 16-slot row holds dW1[k][0..C-1] and db1[k]
+        if (a->V > 6 || !a->ext->dW1 || !a->ext->db1 || !a->ext->dW2 || !a->ext->db2) return 0;
+    }
     if (a->dq.sv != 0 || a->dk_.sv != 0) return 0;
     // the backward reads dy and writes dq / dk / dv with 16-byte vectors, like the forward does q, k, v, y
     const int64_t al = 16 / (a->io_dtype == MOPK_BF16 ? 2 : 4);

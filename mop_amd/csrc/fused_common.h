@@ -199,6 +199,9 @@ __host__ __device__ inline bool fa_drop_keep(const FaDrop &d, uint32_t rowh, int
 }
 
 
+// device pointers of the dense gate head (MopkEdgewiseExt is a host struct): conv1 (16, C) / (16), conv2 (4, 16) / (4)
+struct FusedDenseW { const float *W1, *b1, *W2, *b2; };
+
 // ---- stream GEMM over an LDS operand image -------------------------------------------------------------------------------------
 // For every output tile `to`:  acc = init(to);  acc += Am[32 to + r][:] . Bf;  epi(to, acc).   `am_lane` = Am + r * LDA + 8 * h.
 // The NT x 2NT A-fragment reads form ONE stream that runs PF fragments ahead of the MFMAs.  Reads and their waits are inline asm:

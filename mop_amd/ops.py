@@ -302,9 +302,9 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         a.ext = C.pointer(ext)
         y = torch.empty(B, N, H, dk, dtype=qkv.dtype, device=dev)
         a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
-        # dense head without the 3x3 convolution / lens bank: the fused forward evaluates it inside its mix loop (no backward yet, so
-        # only calls that will not be differentiated take it)
-        if var.dense and not var.use_k3 and not var.lens_dilations and not wants_grad and _PATH != L.PATH_GENERIC:
+        # dense head without the 3x3 convolution / lens bank: the fused kernels evaluate it inside their mix loops (the backward
+        # keeps dW1[k][:] and db1[k] in one 16-slot row, i.e. covers V <= 6)
+        if var.dense and not var.use_k3 and not var.lens_dilations and _PATH != L.PATH_GENERIC and (not wants_grad or V <= 6):
             a.path, a.save_for_backward = L.PATH_FUSED, 1
             if not lib.mopk_edgewise_fused_supported(C.byref(a)):
                 a.path, a.save_for_backward = L.PATH_GENERIC, 0
@@ -327,8 +327,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         qkv, saved, *rest = ctx.saved_tensors
         f = dict(zip(ctx.keys, rest))
         beta_not, V, prec, var, r = ctx.meta
-        if ctx.fwd_path != L.PATH_GENERIC:
-            raise RuntimeError("the fused dense-head forward has no backward; it is only taken for calls that need no gradient")
+        path = ctx.fwd_path
         B, N, Vq, _, H, dk = qkv.shape
         dev = qkv.device
         dy = dy.contiguous()
@@ -336,7 +335,8 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
             dy = dy.to(qkv.dtype)
         a, ext = L.EdgewiseArgs(), L.EdgewiseExt()
         a.B, a.H, a.N, a.dk, a.V, a.r = B, H, N, dk, V, r
-        a.io_dtype, a.precision, a.path, a.beta_not = _io_dtype(qkv), prec, L.PATH_GENERIC, float(beta_not)
+        a.io_dtype, a.precision, a.path, a.beta_not = _io_dtype(qkv), prec, path, float(beta_not)
+        a.save_for_backward = int(path == L.PATH_FUSED)
         _ew_views(a, qkv, "")
         a.sqk, a.vs0, a.vsL, a.chain_logit = f["sqk"].data_ptr(), f["vs0"].data_ptr(), f["vsL"].data_ptr(), f["logit"].data_ptr()
         a.y = L.View4(dy.data_ptr(), N * H * dk, dk, H * dk)
@@ -361,7 +361,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         if var.lens_dilations:
             ext.dlens_w = g["lens_w"].data_ptr()
         a.ext = C.pointer(ext)
-        LAST_PATH["edgewise_bwd"] = L.PATH_GENERIC
+        LAST_PATH["edgewise_bwd"] = path
         ws = _bytes(lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
         a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
         with _timed("edgewise_bwd"):

@@ -78,7 +78,11 @@ def test_edgewise_variants_vs_reference_golden(name, prec):
     assert rel_err(dx, d["dx"]) <= gtol, f"dx rel {rel_err(dx, d['dx']):.3e}"
     check_grads(grads, gref, gtol, floor=1e-3 if prec == "fp32" else 1e-2, d=d if prec == "bf16" else None)
     if meta["gate_mode"] == "dense" or meta["use_lens_bank"]:
-        assert ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_GENERIC
+        # the plain dense head (no 3x3, no lens bank, shared qkv) runs on the fused bf16 kernels; every other variant on the generic path
+        plain = (meta["gate_mode"] == "dense" and not meta["use_k3"] and not meta["use_lens_bank"] and not meta["use_lens_bank_qk"]
+                 and bool(meta["share_qkv"]))
+        want = _lib.PATH_FUSED if (plain and prec == "bf16") else _lib.PATH_GENERIC
+        assert ops.LAST_PATH["edgewise_fwd"] == want and ops.LAST_PATH["edgewise_bwd"] == want
 
 
 @pytest.mark.parametrize("shape", [(3, 17, 64, 4, 3, 2), (2, 64, 128, 2, 5, 4), (1, 197, 128, 2, 5, 4),
@@ -437,8 +441,7 @@ def test_variants_vs_oracle_at_full_sequence_length(variant):
 @pytest.mark.parametrize("shape", [(2, 197, 384, 6, 5), (3, 50, 128, 2, 3), (1, 8, 64, 4, 2), (2, 129, 64, 1, 4), (1, 224, 128, 4, 8)])
 def test_fused_dense_head_forward_vs_oracle_and_generic(shape):
     """dense gate head without the 3x3 convolution (attention_variants.py:250-272 minus :253-254, :312-318) evaluated inside the fused
-    forward's mix loop (bf16 score tiles, fp32 MLP): vs the float64 oracle on bf16-rounded inputs, and vs the generic path.  No fused
-    backward exists yet, so the fused kernel is taken under no_grad only and a differentiated call stays on the generic path."""
+    forward's mix loop (bf16 score tiles, fp32 MLP): vs the float64 oracle on bf16-rounded inputs, and vs the generic path."""
     from oracle import edgewise as oe
     import mop_amd
     from mop_amd import ops, _lib
@@ -472,14 +475,54 @@ def test_fused_dense_head_forward_vs_oracle_and_generic(shape):
         assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_GENERIC
         ops.set_path("auto")
         xr = xg.clone().requires_grad_(True)
-        mg(xr).float().sum().backward()                     # a differentiated call: generic forward + backward
-        assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_GENERIC and torch.isfinite(xr.grad).all()
+        mg(xr).float().sum().backward()                     # a differentiated call: fused too while dW1[k][:] + db1[k] fit one 16-slot row (V <= 6)
+        want = _lib.PATH_FUSED if V <= 6 else _lib.PATH_GENERIC
+        assert ops.LAST_PATH["edgewise_fwd"] == want and ops.LAST_PATH["edgewise_bwd"] == want and torch.isfinite(xr.grad).all()
     finally:
         ops.set_path("auto")
         mop_amd.set_precision("auto")
     scale = max(1.0, float(np.abs(out).max()))
     assert max_abs(y.float().cpu().numpy(), out) <= 1e-2 * scale, f"fused vs oracle {max_abs(y.float().cpu().numpy(), out):.3e}"
     assert max_abs(y.float().cpu().numpy(), yg.float().cpu().numpy()) <= 1.5e-2 * scale
+
+
+@pytest.mark.parametrize("shape", [(2, 197, 384, 6, 5), (3, 50, 128, 2, 3), (1, 8, 64, 4, 2), (2, 129, 64, 1, 4), (2, 33, 64, 2, 6)])
+def test_fused_dense_head_backward_vs_oracle(shape):
+    """training through the fused dense head (launch A: per-edge MLP backward, feature gradients into the hand-off slabs, weight
+    gradients by wave butterflies; launch B: log C<- gradient in the <- chain's seed; launch C: S_v^T feature gradients added
+    transposed) vs the float64 oracle's hand-derived backward."""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import EdgewiseMSA
+    B, N, D, H, V = shape
+    torch.manual_seed(N * 11 + V)
+    m = EdgewiseMSA(D, H, n_views=V, share_qkv=True, gate_mode="dense", use_k3=False, gate_init="and")
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("_scale"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif n_.endswith("conv2.bias"):
+                p.copy_(0.7 * torch.randn_like(p))
+            elif "conv1" in n_ or "conv2" in n_:
+                p.mul_(1.5)
+        m.chain_value_logit.fill_(-0.5)
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, N, D, generator=g).numpy()
+    w = torch.randn(B, N, D, generator=g).numpy()
+    out, cache = oe.module_fwd(x.astype(np.float64), params, H, V, True, 0.5)
+    dx_ref, g_ref = oe.module_bwd(w.astype(np.float64), cache)
+    mop_amd.set_precision("bf16")
+    try:
+        y, dx, grads = run_fwd_bwd(m.cuda().eval(), x, w)
+        assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED and ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_FUSED
+    finally:
+        mop_amd.set_precision("auto")
+    assert max_abs(y, out) <= 1e-2 * max(1.0, float(np.abs(out).max())), f"y {max_abs(y, out):.3e}"
+    assert rel_err(dx, dx_ref) <= 3e-2, f"dx {rel_err(dx, dx_ref):.3e}"
+    noise = oracle_bf16_noise(oe.module_fwd, oe.module_bwd, x, w, params, H, V, True, 0.5)
+    check_grads(grads, g_ref, GTOL_BF16, d=noise)
 
 
 def test_fused_dense_head_forward_vs_reference_fixture():
