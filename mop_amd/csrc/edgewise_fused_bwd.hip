@@ -783,7 +783,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     {
         unsigned short *Qsm = R;                                    // q rows [token][d]: A operand of the S_v^T tiles
         float *wacc = (float *)(R + NP * LDK);                      // [NT][WACC] weight-gradient sums of this (b,h), per wave
-        constexpr int WACC = 16 * 16 + 16 * 4 + 4;                  // dW1 rows [k][16 slots: c < C, slot 15 = db1] | dW2^T [k][m] | db2[m]
+        constexpr int WACC = 16 * 16 + 16 * 4 + 4;                  // [c][k]: dW1[k][c] for c < C <= 14, row 15 = db1[k] | dW2^T [k][m] | db2[m]
         {
             const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
             constexpr int CH = DK / 8;
@@ -812,17 +812,34 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             return acc;
         };
         // sum over the 64 lanes of sixteen per-lane values: after four halving exchanges lane l holds the sum (over its 16-lane row) of
-        // value idx(l) = 8 b0 + 4 b1 + 2 b2 + b3 (b_i = bit i of l), two more exchanges add the four rows
+        // value idx(l) = 8 b0 + 4 b1 + 2 b2 + b3 (b_i = bit i of l), two more exchanges add the four rows.  The exchanges inside a row
+        // are DPP moves (quad_perm for xor 1 / 2, a row_shl / row_shr pair for xor 4 / 8: VALU rate, no LDS crossbar)
+        auto xchg = [&](float x, int step) -> float {                   // value of lane (l ^ step), step in {1, 2, 4, 8}
+            const int xi = __builtin_bit_cast(int, x);
+            int y;
+            if (step == 1) y = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xf, 0xf, true);           // quad_perm [1,0,3,2]
+            else if (step == 2) y = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+            else if (step == 4) {
+                const int up = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xf, 0xf, true);          // row_shl:4 (from lane + 4)
+                const int dn = __builtin_amdgcn_update_dpp(0, xi, 0x114, 0xf, 0xf, true);          // row_shr:4 (from lane - 4)
+                y = (lane & 4) ? dn : up;
+            } else {
+                const int up = __builtin_amdgcn_update_dpp(0, xi, 0x108, 0xf, 0xf, true);
+                const int dn = __builtin_amdgcn_update_dpp(0, xi, 0x118, 0xf, 0xf, true);
+                y = (lane & 8) ? dn : up;
+            }
+            return __builtin_bit_cast(float, y);
+        };
         auto reduce16 = [&](const float (&v)[16]) -> float {
             float a8[8], a4[4], a2[2];
             const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a8[i] = (b0 ? v[8 + i] : v[i]) + __shfl_xor(b0 ? v[i] : v[8 + i], 1, 64);
+            for (int i = 0; i < 8; ++i) a8[i] = (b0 ? v[8 + i] : v[i]) + xchg(b0 ? v[i] : v[8 + i], 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a4[i] = (b1 ? a8[4 + i] : a8[i]) + __shfl_xor(b1 ? a8[i] : a8[4 + i], 2, 64);
+            for (int i = 0; i < 4; ++i) a4[i] = (b1 ? a8[4 + i] : a8[i]) + xchg(b1 ? a8[i] : a8[4 + i], 2);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a2[i] = (b2 ? a4[2 + i] : a4[i]) + __shfl_xor(b2 ? a4[i] : a4[2 + i], 4, 64);
-            float s = (b3 ? a2[1] : a2[0]) + __shfl_xor(b3 ? a2[0] : a2[1], 8, 64);
+            for (int i = 0; i < 2; ++i) a2[i] = (b2 ? a4[2 + i] : a4[i]) + xchg(b2 ? a4[i] : a4[2 + i], 4);
+            float s = (b3 ? a2[1] : a2[0]) + xchg(b3 ? a2[0] : a2[1], 8);
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             return s;
@@ -831,11 +848,18 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         const IOT *krow = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh + (int64_t)qi * a.k.sn;
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            bf16x8 qraw_t[KS], kraw_t[KS], dyf_t[KS];
+            // the q / k fragments of this lane's token and the tile's dP stay resident across the quarters.  (Re-reading them inside the
+            // quarter body instead cut the spills of this launch from 290 to 135 registers and its time by a fifth, but that variant
+            // faulted in the NT = 1 instantiation -- an address formed in a divergent region and reused -- and is not in the tree.)
+            bf16x8 qraw_t[KS], kraw_t[KS];
             make_frag(qraw_t, qrow, nullptr);
             make_frag(kraw_t, krow, nullptr);
-            make_frag(dyf_t, dyrow, nullptr);
-            const f32x16 dPt = g_tile(V0s, dyf_t, t);              // dP = dy v0^T for the whole tile; quarters index into it
+            f32x16 dPt;
+            {
+                bf16x8 dyf_t[KS];
+                make_frag(dyf_t, dyrow, nullptr);
+                dPt = g_tile(V0s, dyf_t, t);                        // dP = dy v0^T for the whole tile; quarters index into it
+            }
 #pragma nounroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int hi8 = q4 >> 1, lo2 = q4 & 1;             // this quarter = dwords 2 lo2, 2 lo2 + 1 of the (lo | hi) 16-byte half of a packed tile
@@ -861,11 +885,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         Clq[e] = __logf(bf2f((unsigned short)(cbw[e >> 1] >> (16 * (e & 1)))) + EPSC);
                     }
                 }
-                // ---- features and first layer: z1[k][e] = b1[k] + sum_c W1[k][c] f_c[e]
-                f32x16 F[4];                                        // F[e][c]: channel c of edge e (c < C <= 14; slots C.. stay 0)
-                float z1[16][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) F[e] = zero16();
+                // ---- features and first layer: z1[e][k] = b1[k] + sum_c W1[k][c] f_c[e]
+                f32x16 z1[4];                                       // z1[k][e]: pre-activation (later dz1) of hidden unit k for edge e; k may be a runtime index
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
@@ -873,11 +894,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = bb[kk];
+                        for (int e = 0; e < 4; ++e) z1[e][4 * k4 + kk] = bb[kk];
                 }
                 auto accum = [&](int c, const float (&f)[4]) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) F[e][c] = f[e];
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
@@ -885,7 +904,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = fmaf(ww[kk], f[e], z1[4 * k4 + kk][e]);
+                            for (int e = 0; e < 4; ++e) z1[e][4 * k4 + kk] = fmaf(ww[kk], f[e], z1[e][4 * k4 + kk]);
                     }
                 };
                 float Oq[4] = {0.f, 0.f, 0.f, 0.f}, S0q[4];
@@ -916,13 +935,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) zz[m][e] = bb[m];
                 }
-#pragma unroll
+#pragma nounroll
                 for (int k = 0; k < 16; ++k) {
                     const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
                     const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float u = z1[k][e];
+                        const float u = z1[e][k];
                         const float hv = u * __builtin_amdgcn_rcpf(1.f + __expf(-1.5957691216057308f * (u + 0.044715f * u * u * u)));
 #pragma unroll
                         for (int m = 0; m < 4; ++m) zz[m][e] = fmaf(ww[m], hv, zz[m][e]);
@@ -945,16 +964,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     for (int m = 0; m < 4; ++m) pb[m] = wave_sum((dzz[m][0] + dzz[m][1]) + (dzz[m][2] + dzz[m][3]));
                     if (lane < 4) wme[16 * 16 + 16 * 4 + lane] += lane == 0 ? pb[0] : lane == 1 ? pb[1] : lane == 2 ? pb[2] : pb[3];
                 }
-#pragma unroll
+#pragma nounroll
                 for (int k = 0; k < 16; ++k) {
                     const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
                     const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
-                    float pw2[4] = {0.f, 0.f, 0.f, 0.f}, row[16];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) row[c] = 0.f;
+                    float pw2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float u = z1[k][e];
+                        const float u = z1[e][k];
                         const float arg = 1.5957691216057308f * (u + 0.044715f * u * u * u);
                         const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-arg));
                         const float hv = u * sg;
@@ -963,13 +980,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int m = 0; m < 4; ++m) { dh = fmaf(ww[m], dzz[m][e], dh); pw2[m] = fmaf(dzz[m][e], hv, pw2[m]); }
                         const float d1 = dh * gp;
-                        z1[k][e] = d1;                               // dz1
-#pragma unroll
-                        for (int c = 0; c < 15; ++c) row[c] = fmaf(d1, F[e][c], row[c]);
-                        row[15] += d1;                               // db1
+                        z1[e][k] = d1;                               // dz1
                     }
-                    const float rs = reduce16(row);
-                    if ((lane >> 4) == 0) wme[16 * k + ridx] += rs;
                     {   // dW2^T row k: four values; two halving steps, then four plain ones
                         const bool b0 = lane & 1, b1 = lane & 2;
                         float a2[2];
@@ -980,26 +992,51 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         if (lane < 4) wme[16 * 16 + 4 * k + (((lane & 1) << 1) | ((lane & 2) >> 1))] += s;
                     }
                 }
-                // ---- df_c = sum_k W1[k][c] dz1[k]  ->  hand-off slabs
+                // ---- second pass over the channels: the feature quarter is recomputed (matrix core), dW1[:, c] = sum_e dz1[:, e] f_c[e]
+                //      reduced over the wave (16 hidden units = one butterfly), df_c = sum_k W1[k][c] dz1[k] -> hand-off slabs
                 float g1q[4], gAq[4], lseq[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { g1q[e] = G[1][e]; gAq[e] = fmaf(-nb, G[2][e], G[0][e]); lseq[e] = Lq[e] + S0q[e]; }
+                {
+                    float row[16];                                   // db1[k] = sum_e dz1[e][k]
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) row[k] = (z1[0][k] + z1[1][k]) + (z1[2][k] + z1[3][k]);
+                    const float rs = reduce16(row);
+                    if ((lane >> 4) == 0) wme[16 * 15 + ridx] += rs;      // slot row 15 of the [c][k] table (C <= 14)
+                }
                 for (int c = 0; c < C; ++c) {
-                    float df[4] = {0.f, 0.f, 0.f, 0.f};
+                    float f[4];
+                    if (c < 2 * V) {
+                        bf16x8 qe[KS];
+                        const int v = c < V ? c : c - V;
+                        if (c < V) scale_frag(qe, qraw_t, sqk + v * DK); else scale_frag(qe, kraw_t, sqk + v * DK);
+                        const f32x16 Sv = c < V ? s_tile(qe, t) : st_tile(qe, t);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = Sv[4 * q4 + e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) f[e] = c == 2 * V ? Crq[e] : Clq[e];
+                    }
+                    float row[16], df[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
                         const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int k = 4 * k4 + kk;
+                            row[k] = fmaf(z1[0][k], f[0], fmaf(z1[1][k], f[1], fmaf(z1[2][k], f[2], z1[3][k] * f[3])));
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) df[e] = fmaf(ww[kk], z1[4 * k4 + kk][e], df[e]);
+                            for (int e = 0; e < 4; ++e) df[e] = fmaf(ww[kk], z1[e][k], df[e]);
+                        }
                     }
+                    const float rs = reduce16(row);
+                    if ((lane >> 4) == 0) wme[16 * c + ridx] += rs;       // [c][k]: dW1[k][c]
                     if (c < V) {                                      // S_v channel: direct score gradient dSmix * coef_v + df
                         float o[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float pi = __expf(F[e][c] - lseq[e]);
+                            const float pi = __expf(f[e] - lseq[e]);
                             const float coef = c == 0 ? (1.f - g1q[e]) + g1q[e] * pi : fmaf(g1q[e], pi, gAq[e]);
                             o[e] = fmaf(dSq[e], coef, df[e]);
                         }
@@ -1547,7 +1584,7 @@ void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipS
     const int nout = 2 * 4 * a->r * (2 * a->V + 3);
     hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3(nout), dim3(256), 0, st, *a, W, nwg);
 }
-// dense head: per-workgroup partials [16 rows x 16 slots (dW1[k][c < C], slot 15 = db1[k]) | dW2^T [k][m] | db2[m]] -> conv1 / conv2 gradients
+// dense head: per-workgroup partials [[c][k] table: dW1[k][c] for c < C, row 15 = db1[k] | dW2^T [k][m] | db2[m]] -> conv1 / conv2 gradients
 struct DenseGradOut { float *dW1, *db1, *dW2, *db2; };
 __global__ void ew_fused_dense_dw_reduce_kernel(BwdWs W, int nwg, int C, DenseGradOut o) {
     __shared__ float red[256];
@@ -1558,7 +1595,7 @@ __global__ void ew_fused_dense_dw_reduce_kernel(BwdWs W, int nwg, int C, DenseGr
     for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
     if (threadIdx.x != 0) return;
     s = red[0];
-    if (idx < 256) { const int k = idx / 16, c = idx % 16; if (c < C) o.dW1[k * C + c] = s; else if (c == 15) o.db1[k] = s; }
+    if (idx < 256) { const int c = idx / 16, k = idx % 16; if (c < C) o.dW1[k * C + c] = s; else if (c == 15) o.db1[k] = s; }
     else if (idx < 320) { const int k = (idx - 256) / 4, m = (idx - 256) % 4; o.dW2[m * 16 + k] = s; }
     else o.db2[idx - 320] = s;
 }
