@@ -77,7 +77,9 @@ typedef struct MopkView5 {
  *   sqk_v = q_scale_v * k_scale_v / sqrt(dk).
  * For share_qkv=False pass per-view q/k (sv != 0) and sqk = 1/sqrt(dk).
  * -------------------------------------------------------------------------- */
-/* Optional gate-head / feature variants (generic path only; NULL ext = low-rank head, no lens bank).
+/* Optional gate-head / feature variants (NULL ext = low-rank head, no lens bank).  The plain dense head (use_k3 = 0, n_lens = 0,
+ * shared q/k, V <= 8 forward / V <= 6 backward, save_for_backward = 1) also runs on the fused kernels (MOPK_PATH_FUSED); the 3x3
+ * convolution and the lens banks are generic-path only.
  *   dense head  : reference EdgewiseGateHead dense branch :250-272, :312-318 (Conv2d 1x1 C->16, GELU(tanh),
  *                 [use_k3: GELU again, Conv2d 3x3 16->16 pad 1], Conv2d 1x1 16->4, sigmoid)
  *   S lens bank : depthwise dilated 3x3 convolutions of the score planes appended to the feature stack :425-442, :523-533
