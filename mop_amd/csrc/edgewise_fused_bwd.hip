@@ -848,9 +848,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         const IOT *krow = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh + (int64_t)qi * a.k.sn;
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            // the q / k fragments of this lane's token and the tile's dP stay resident across the quarters.  (Re-reading them inside the
-            // quarter body instead cut the spills of this launch from 290 to 135 registers and its time by a fifth, but that variant
-            // faulted in the NT = 1 instantiation -- an address formed in a divergent region and reused -- and is not in the tree.)
+            // the q / k fragments of this lane's token and the tile's dP stay resident across the register groups
             bf16x8 qraw_t[KS], kraw_t[KS];
             make_frag(qraw_t, qrow, nullptr);
             make_frag(kraw_t, krow, nullptr);
@@ -860,33 +858,40 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 make_frag(dyf_t, dyrow, nullptr);
                 dPt = g_tile(V0s, dyf_t, t);                        // dP = dy v0^T for the whole tile; quarters index into it
             }
+            // E edges per lane and pass: registers E qq .. E qq + E - 1 of the tile.  E = 2 keeps the body (32 pre-activations, the held
+            // fragments, the butterfly rows) inside the register budget; with E = 4 it spilled 290 registers and the launch was bound
+            // by its own scratch traffic.  The price is twice the score-tile recompute, which the idle matrix pipe absorbs.
+            constexpr int E = 2, NQ = 16 / E;
 #pragma nounroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int hi8 = q4 >> 1, lo2 = q4 & 1;             // this quarter = dwords 2 lo2, 2 lo2 + 1 of the (lo | hi) 16-byte half of a packed tile
-                auto piece = [&](const u32x4 *p) -> uint2 { return ((const uint2 *)&p[(2 * t + hi8) * 64])[lo2]; };
-                auto put = [&](u32x4 *p, float x0, float x1, float x2, float x3) {
-                    ((uint2 *)&p[(2 * t + hi8) * 64])[lo2] = make_uint2(pack_bf16(x0, x1), pack_bf16(x2, x3));
-                };
-                float dSq[4], Lq[4], Crq[4], Clq[4];
+            for (int qq = 0; qq < NQ; ++qq) {
+                const int g0 = E * qq;                                // first register of this group (even)
+                // packed tiles hold elements 2d, 2d + 1 in dword d of the (lo | hi) pair of 16-byte vectors
+                auto getw = [&](const u32x4 *p, int g) -> unsigned int { return ((const unsigned int *)&p[(2 * t + (g >> 3)) * 64])[(g >> 1) & 3]; };
+                auto putw = [&](u32x4 *p, int g, float x0, float x1) { ((unsigned int *)&p[(2 * t + (g >> 3)) * 64])[(g >> 1) & 3] = pack_bf16(x0, x1); };
+                float dSq[E], Lq[E], Crq[E], Clq[E];
                 {
-                    const uint2 sm = piece(slot(S_SM)), cf = piece(slot(S_CF)), cb = piece(slot(S_CB));
-                    const f32x4 l4 = ((const f32x4 *)(svb + SL.oL + (size_t)w * 2 * Cfg::SLOT) + lane)[(4 * t + q4) * 64];
-                    const float smx[4] = {h2_lo(sm.x), h2_hi(sm.x), h2_lo(sm.y), h2_hi(sm.y)};
-                    const unsigned int cfw[2] = {cf.x, cf.y}, cbw[2] = {cb.x, cb.y};
+                    const float *lp = (const float *)((const f32x4 *)(svb + SL.oL + (size_t)w * 2 * Cfg::SLOT) + lane);     // [4 t + q][lane] x 16 B
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int j = 32 * t + tile_row(4 * q4 + e, h);
-                        float dp = dPt[4 * q4 + e];
-                        if (drop.thresh) dp = fa_drop_keep(drop, rowh, j) ? dp * drop.inv_keep : 0.f;
-                        const float P = __expf(smx[e] - mxrow) * invl;
-                        dSq[e] = keep_if(j < N, P * (dp - delta));
-                        Lq[e] = l4[e] * 0.6931471805599453f;
-                        Crq[e] = __logf(bf2f((unsigned short)(cfw[e >> 1] >> (16 * (e & 1)))) + EPSC);
-                        Clq[e] = __logf(bf2f((unsigned short)(cbw[e >> 1] >> (16 * (e & 1)))) + EPSC);
+                    for (int e2 = 0; e2 < E; e2 += 2) {
+                        const int g = g0 + e2;
+                        const unsigned int sm = getw(slot(S_SM), g), cf = getw(slot(S_CF), g), cb = getw(slot(S_CB), g);
+                        const float2 l2 = *(const float2 *)&lp[(size_t)(4 * t + (g >> 2)) * 64 * 4 + (g & 3)];
+                        const float smx[2] = {h2_lo(sm), h2_hi(sm)}, lv[2] = {l2.x, l2.y};
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int j = 32 * t + tile_row(g + e, h);
+                            float dp = dPt[g + e];
+                            if (drop.thresh) dp = fa_drop_keep(drop, rowh, j) ? dp * drop.inv_keep : 0.f;
+                            const float P = __expf(smx[e] - mxrow) * invl;
+                            dSq[e2 + e] = keep_if(j < N, P * (dp - delta));
+                            Lq[e2 + e] = lv[e] * 0.6931471805599453f;
+                            Crq[e2 + e] = __logf(bf2f((unsigned short)(cf >> (16 * e))) + EPSC);
+                            Clq[e2 + e] = __logf(bf2f((unsigned short)(cb >> (16 * e))) + EPSC);
+                        }
                     }
                 }
                 // ---- features and first layer: z1[e][k] = b1[k] + sum_c W1[k][c] f_c[e]
-                f32x16 z1[4];                                       // z1[k][e]: pre-activation (later dz1) of hidden unit k for edge e; k may be a runtime index
+                f32x16 z1[E];                                       // z1[e][k]: pre-activation (later dz1) of hidden unit k for edge e; k may be a runtime index
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
@@ -894,9 +899,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) z1[e][4 * k4 + kk] = bb[kk];
+                        for (int e = 0; e < E; ++e) z1[e][4 * k4 + kk] = bb[kk];
                 }
-                auto accum = [&](int c, const float (&f)[4]) {
+                auto accum = [&](int c, const float (&f)[E]) {
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
@@ -904,52 +909,58 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) z1[e][4 * k4 + kk] = fmaf(ww[kk], f[e], z1[e][4 * k4 + kk]);
+                            for (int e = 0; e < E; ++e) z1[e][4 * k4 + kk] = fmaf(ww[kk], f[e], z1[e][4 * k4 + kk]);
                     }
                 };
-                float Oq[4] = {0.f, 0.f, 0.f, 0.f}, S0q[4];
+                float Oq[E], S0q[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) { Oq[e] = 0.f; S0q[e] = 0.f; }
                 {
                     bf16x8 qe[KS];
                     for (int v = 0; v < V; ++v) {
                         scale_frag(qe, qraw_t, sqk + v * DK);
                         const f32x16 Sv = s_tile(qe, t);
-                        const float fs4[4] = {Sv[4 * q4], Sv[4 * q4 + 1], Sv[4 * q4 + 2], Sv[4 * q4 + 3]};
-                        accum(v, fs4);
+                        float fs[E];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { if (v == 0) S0q[e] = fs4[e]; else Oq[e] += fs4[e]; }
+                        for (int e = 0; e < E; ++e) fs[e] = Sv[g0 + e];
+                        accum(v, fs);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) { if (v == 0) S0q[e] = fs[e]; else Oq[e] += fs[e]; }
                         scale_frag(qe, kraw_t, sqk + v * DK);
                         const f32x16 Tv = st_tile(qe, t);
-                        const float ft4[4] = {Tv[4 * q4], Tv[4 * q4 + 1], Tv[4 * q4 + 2], Tv[4 * q4 + 3]};
-                        accum(V + v, ft4);
+                        float ft[E];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) ft[e] = Tv[g0 + e];
+                        accum(V + v, ft);
                     }
                 }
                 accum(2 * V, Crq);
                 accum(2 * V + 1, Clq);
                 // ---- second layer and gates
-                float zz[4][4];
+                float zz[4][E];
                 {
                     const float4 bv = *(const float4 *)&Wsm[384];
                     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) zz[m][e] = bb[m];
+                        for (int e = 0; e < E; ++e) zz[m][e] = bb[m];
                 }
 #pragma nounroll
                 for (int k = 0; k < 16; ++k) {
                     const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
                     const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < E; ++e) {
                         const float u = z1[e][k];
                         const float hv = u * __builtin_amdgcn_rcpf(1.f + __expf(-1.5957691216057308f * (u + 0.044715f * u * u * u)));
 #pragma unroll
                         for (int m = 0; m < 4; ++m) zz[m][e] = fmaf(ww[m], hv, zz[m][e]);
                     }
                 }
-                float G[4][4], dzz[4][4];
+                float G[4][E], dzz[4][E];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < E; ++e) {
                     const float term[4] = {Oq[e], Lq[e], -nb * Oq[e], Crq[e]};    // d Smix / d G_g: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
@@ -957,11 +968,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         dzz[m][e] = dSq[e] * term[m] * G[m][e] * (1.f - G[m][e]);
                     }
                 }
-                // ---- db2, then per hidden unit: h, gelu', dh, dz1 (in place of z1), dW2^T row, dW1 row
+                // ---- db2, then per hidden unit: h, gelu', dh, dz1 (in place of z1), dW2^T row
                 {
                     float pb[4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) pb[m] = wave_sum((dzz[m][0] + dzz[m][1]) + (dzz[m][2] + dzz[m][3]));
+                    for (int m = 0; m < 4; ++m) { float sacc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) sacc += dzz[m][e];
+                        pb[m] = wave_sum(sacc); }
                     if (lane < 4) wme[16 * 16 + 16 * 4 + lane] += lane == 0 ? pb[0] : lane == 1 ? pb[1] : lane == 2 ? pb[2] : pb[3];
                 }
 #pragma nounroll
@@ -970,7 +984,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                     const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
                     float pw2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < E; ++e) {
                         const float u = z1[e][k];
                         const float arg = 1.5957691216057308f * (u + 0.044715f * u * u * u);
                         const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-arg));
@@ -979,45 +993,49 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         float dh = 0.f;
 #pragma unroll
                         for (int m = 0; m < 4; ++m) { dh = fmaf(ww[m], dzz[m][e], dh); pw2[m] = fmaf(dzz[m][e], hv, pw2[m]); }
-                        const float d1 = dh * gp;
-                        z1[e][k] = d1;                               // dz1
+                        z1[e][k] = dh * gp;                          // dz1
                     }
                     {   // dW2^T row k: four values; two halving steps, then four plain ones
                         const bool b0 = lane & 1, b1 = lane & 2;
                         float a2[2];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) a2[i] = (b0 ? pw2[2 + i] : pw2[i]) + __shfl_xor(b0 ? pw2[i] : pw2[2 + i], 1, 64);
-                        float s = (b1 ? a2[1] : a2[0]) + __shfl_xor(b1 ? a2[0] : a2[1], 2, 64);
-                        s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-                        if (lane < 4) wme[16 * 16 + 4 * k + (((lane & 1) << 1) | ((lane & 2) >> 1))] += s;
+                        for (int i = 0; i < 2; ++i) a2[i] = (b0 ? pw2[2 + i] : pw2[i]) + xchg(b0 ? pw2[i] : pw2[2 + i], 1);
+                        float sred = (b1 ? a2[1] : a2[0]) + xchg(b1 ? a2[0] : a2[1], 2);
+                        sred += xchg(sred, 4); sred += xchg(sred, 8); sred += __shfl_xor(sred, 16, 64); sred += __shfl_xor(sred, 32, 64);
+                        if (lane < 4) wme[16 * 16 + 4 * k + (((lane & 1) << 1) | ((lane & 2) >> 1))] += sred;
                     }
                 }
-                // ---- second pass over the channels: the feature quarter is recomputed (matrix core), dW1[:, c] = sum_e dz1[:, e] f_c[e]
+                // ---- second pass over the channels: the feature group is recomputed (matrix core), dW1[:, c] = sum_e dz1[:, e] f_c[e]
                 //      reduced over the wave (16 hidden units = one butterfly), df_c = sum_k W1[k][c] dz1[k] -> hand-off slabs
-                float g1q[4], gAq[4], lseq[4];
+                float g1q[E], gAq[E], lseq[E];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { g1q[e] = G[1][e]; gAq[e] = fmaf(-nb, G[2][e], G[0][e]); lseq[e] = Lq[e] + S0q[e]; }
+                for (int e = 0; e < E; ++e) { g1q[e] = G[1][e]; gAq[e] = fmaf(-nb, G[2][e], G[0][e]); lseq[e] = Lq[e] + S0q[e]; }
                 {
                     float row[16];                                   // db1[k] = sum_e dz1[e][k]
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) row[k] = (z1[0][k] + z1[1][k]) + (z1[2][k] + z1[3][k]);
+                    for (int k = 0; k < 16; ++k) { float sacc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) sacc += z1[e][k];
+                        row[k] = sacc; }
                     const float rs = reduce16(row);
                     if ((lane >> 4) == 0) wme[16 * 15 + ridx] += rs;      // slot row 15 of the [c][k] table (C <= 14)
                 }
                 for (int c = 0; c < C; ++c) {
-                    float f[4];
+                    float f[E];
                     if (c < 2 * V) {
                         bf16x8 qe[KS];
                         const int v = c < V ? c : c - V;
                         if (c < V) scale_frag(qe, qraw_t, sqk + v * DK); else scale_frag(qe, kraw_t, sqk + v * DK);
                         const f32x16 Sv = c < V ? s_tile(qe, t) : st_tile(qe, t);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] = Sv[4 * q4 + e];
+                        for (int e = 0; e < E; ++e) f[e] = Sv[g0 + e];
                     } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) f[e] = c == 2 * V ? Crq[e] : Clq[e];
+                        for (int e = 0; e < E; ++e) f[e] = c == 2 * V ? Crq[e] : Clq[e];
                     }
-                    float row[16], df[4] = {0.f, 0.f, 0.f, 0.f};
+                    float row[16], df[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) df[e] = 0.f;
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
@@ -1025,29 +1043,29 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) {
                             const int k = 4 * k4 + kk;
-                            row[k] = fmaf(z1[0][k], f[0], fmaf(z1[1][k], f[1], fmaf(z1[2][k], f[2], z1[3][k] * f[3])));
+                            float sacc = 0.f;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) df[e] = fmaf(ww[kk], z1[e][k], df[e]);
+                            for (int e = 0; e < E; ++e) { sacc = fmaf(z1[e][k], f[e], sacc); df[e] = fmaf(ww[kk], z1[e][k], df[e]); }
+                            row[k] = sacc;
                         }
                     }
                     const float rs = reduce16(row);
                     if ((lane >> 4) == 0) wme[16 * c + ridx] += rs;       // [c][k]: dW1[k][c]
-                    if (c < V) {                                      // S_v channel: direct score gradient dSmix * coef_v + df
-                        float o[4];
+                    // one store site for every channel kind (the slab id and the value are selected arithmetically): S_v channels -> DIR_v
+                    // (direct score gradient dSmix * coef_v + df), S_v^T channels -> their own slabs (gradient of S_v(j, i), added transposed
+                    // by launch C), Cr -> C3 (joins the chain-gate term G_chain dSmix), Cl -> the slab that seeds the <- D-chain (launch B)
+                    const int sid = c < V ? X_DIR + c : (c < 2 * V ? X_DT(V) + (c - V) : (c == 2 * V ? (int)X_C3 : X_CL(V)));
+                    float o[E];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float pi = __expf(f[e] - lseq[e]);
-                            const float coef = c == 0 ? (1.f - g1q[e]) + g1q[e] * pi : fmaf(g1q[e], pi, gAq[e]);
-                            o[e] = fmaf(dSq[e], coef, df[e]);
-                        }
-                        put(slot(X_DIR + c), o[0], o[1], o[2], o[3]);
-                    } else if (c < 2 * V) {                           // S_v^T channel: gradient of S_v(j, i), added transposed by launch C
-                        put(slot(X_DT(V) + (c - V)), df[0], df[1], df[2], df[3]);
-                    } else if (c == 2 * V) {                          // Cr: joins the chain-gate term G_chain dSmix
-                        put(slot(X_C3), fmaf(dSq[0], G[3][0], df[0]), fmaf(dSq[1], G[3][1], df[1]), fmaf(dSq[2], G[3][2], df[2]), fmaf(dSq[3], G[3][3], df[3]));
-                    } else {                                          // Cl: seeds the <- D-chain (launch B)
-                        put(slot(X_CL(V)), df[0], df[1], df[2], df[3]);
+                    for (int e = 0; e < E; ++e) {
+                        const float pi = __expf(fminf(f[e] - lseq[e], 0.f));          // only meaningful for the S_v channels (pi <= 1 there)
+                        const float coef = c == 0 ? (1.f - g1q[e]) + g1q[e] * pi : fmaf(g1q[e], pi, gAq[e]);
+                        const float direct = c < V ? dSq[e] * coef : (c == 2 * V ? dSq[e] * G[3][e] : 0.f);
+                        o[e] = direct + df[e];
                     }
+                    u32x4 *ps = slot(sid);
+#pragma unroll
+                    for (int e2 = 0; e2 < E; e2 += 2) putw(ps, g0 + e2, o[e2], o[e2 + 1]);
                 }
             }
         }
