@@ -171,9 +171,9 @@ class EdgewiseMSA(nn.Module):
         if self.use_lens_bank and self.lens_kernel_size != 3:
             raise ValueError("lens_kernel_size must be 3: with padding = dilation any other size changes the plane size and "
                              "the reference's feature stack (:534) cannot be built")
-        if self.training and self.attn_drop.p > 0 and (self.edge_head.gate_mode == "dense" or self.use_lens_bank):
-            raise NotImplementedError("attn_drop > 0 in training mode: the fused low-rank kernels carry it, the dense-head / "
-                                      "lens-bank variants (generic path) do not")
+        if self.training and self.attn_drop.p > 0 and (self.use_lens_bank or (self.edge_head.gate_mode == "dense" and self.edge_head.use_k3)):
+            raise NotImplementedError("attn_drop > 0 in training mode: the fused kernels carry it (low-rank head, plain dense head); "
+                                      "the use_k3 / lens-bank variants (generic path) do not")
 
     def _qk_lens_views(self, qkv: torch.Tensor) -> torch.Tensor:
         """Q/K lens bank (:472-498): depthwise dilated convolutions over the token axis of view-0 q and k build one
@@ -246,7 +246,7 @@ class EdgewiseMSA(nn.Module):
             head = (eh.row_proj.weight.squeeze(-1), eh.row_proj.bias, eh.col_proj.weight.squeeze(-1), eh.col_proj.bias)
             W3 = b3 = None
         y = ops.edgewise_general_core(qkv, sqk, vs0, vsL, self.chain_value_logit, head, float(self.beta_not), n_s, var,
-                                      W3=W3, b3=b3, lens_w=lens_w)
+                                      W3=W3, b3=b3, lens_w=lens_w, dropout_p=float(self.attn_drop.p) if self.training else 0.0)
         return self._project(y, residual)
 
 

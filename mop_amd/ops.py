@@ -279,7 +279,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
     (unused ones are passed as empty tensors)."""
 
     @staticmethod
-    def forward(ctx, qkv, sqk, vs0, vsL, logit, h0, h1, h2, h3, W3, b3, lens_w, beta_not, V, prec, var, wants_grad=True):
+    def forward(ctx, qkv, sqk, vs0, vsL, logit, h0, h1, h2, h3, W3, b3, lens_w, beta_not, V, prec, var, wants_grad=True, drop=(0.0, 0)):
         _require_gpu(qkv, "EdgewiseMSA")
         lib = L.lib()
         B, N, Vq, _, H, dk = qkv.shape
@@ -308,6 +308,10 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
             a.path, a.save_for_backward = L.PATH_FUSED, 1
             if not lib.mopk_edgewise_fused_supported(C.byref(a)):
                 a.path, a.save_for_backward = L.PATH_GENERIC, 0
+        if drop[0] > 0 and a.path != L.PATH_FUSED:
+            raise NotImplementedError("attn_drop > 0 in training mode: carried by the fused kernels only (low-rank head, or the dense "
+                                      "head without use_k3 / lens banks at V <= 6, bf16 arithmetic)")
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         LAST_PATH["edgewise_fwd"] = int(a.path)
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
         ws = _bytes(256 if a.path == L.PATH_FUSED else lib.mopk_edgewise_workspace_bytes(C.byref(a)), dev)
@@ -318,7 +322,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         ctx.save_for_backward(qkv, saved, *f.values())
         ctx.keys = list(f.keys())
         ctx.meta = (beta_not, V, prec, var, int(a.r))
-        ctx.fwd_path = int(a.path)
+        ctx.fwd_path, ctx.drop = int(a.path), drop
         return y.view(B, N, H * dk)
 
     @staticmethod
@@ -337,6 +341,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         a.B, a.H, a.N, a.dk, a.V, a.r = B, H, N, dk, V, r
         a.io_dtype, a.precision, a.path, a.beta_not = _io_dtype(qkv), prec, path, float(beta_not)
         a.save_for_backward = int(path == L.PATH_FUSED)
+        a.dropout_p, a.dropout_seed = float(ctx.drop[0]), int(ctx.drop[1])
         _ew_views(a, qkv, "")
         a.sqk, a.vs0, a.vsL, a.chain_logit = f["sqk"].data_ptr(), f["vs0"].data_ptr(), f["vsL"].data_ptr(), f["logit"].data_ptr()
         a.y = L.View4(dy.data_ptr(), N * H * dk, dk, H * dk)
@@ -368,21 +373,23 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
             rc = lib.mopk_edgewise_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_bwd")
         return (dqkv, dsqk.sum(0), dvs0.sum(0), dvsL.sum(0), dlg.sum().reshape(()), g["h0"], g["h1"], g["h2"], g["h3"],
-                g["W3"], g["b3"], g["lens_w"], None, None, None, None, None)
+                g["W3"], g["b3"], g["lens_w"], None, None, None, None, None, None)
 
 
 def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float, n_views: int, variant: EdgewiseVariant,
-                          W3=None, b3=None, lens_w=None, precision: Optional[int] = None):
+                          W3=None, b3=None, lens_w=None, precision: Optional[int] = None, dropout_p: float = 0.0,
+                          seed: Optional[int] = None):
     """EdgewiseMSA core for the dense gate head and/or the S lens bank.  head = (Wr, br, Wc, bc) for the low-rank head
     with C = 2V+2+L*V input channels, or (W1 (16,C), b1, W2 (4,16), b2) for the dense head; W3/b3 with use_k3;
     lens_w (L,V,3,3).  qkv as in edgewise_lowrank_core."""
     prec = _prec_for(qkv.dtype) if precision is None else precision
     e = qkv.new_zeros(0, dtype=torch.float32)
+    drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     # decided here: inside Function.forward autograd is already switched off
     wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
                                                  for t in (qkv, sqk, vs0, vsL, chain_logit, *head, W3, b3, lens_w))
     return _EdgewiseGeneralFn.apply(qkv, sqk, vs0, vsL, chain_logit, *head, e if W3 is None else W3, e if b3 is None else b3,
-                                    e if lens_w is None else lens_w, beta_not, n_views, prec, variant, wants_grad)
+                                    e if lens_w is None else lens_w, beta_not, n_views, prec, variant, wants_grad, drop)
 
 
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,

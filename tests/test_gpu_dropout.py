@@ -119,7 +119,7 @@ def test_quartet_dropout_matches_the_oracle_under_the_same_mask(use_quartet):
         assert abs(float(qs.grad) - float(g["dquartet_scale"])) <= 5e-2 * max(abs(float(g["dquartet_scale"])), 1e-3)
 
 
-@pytest.mark.parametrize("save_chain", [True, False])
+@pytest.mark.parametrize("save_chain", [True, False, "dense"])
 def test_edgewise_dropout_matches_the_oracle_under_the_same_mask(save_chain):
     """EdgewiseMSA(lowrank) in training mode with attn_drop (:552) on the fused kernels; both backward modes (saved chain state /
     forward re-run inside the backward, which must reproduce the same mask)."""
@@ -130,10 +130,15 @@ def test_edgewise_dropout_matches_the_oracle_under_the_same_mask(save_chain):
     from gpu_util import check_grads, oracle_bf16_noise
     D, Hh, V, N, B, p = 128, 2, 3, 50, 3, 0.2
     torch.manual_seed(21)
-    m = EdgewiseMSA(D, Hh, attn_drop=p, n_views=V, share_qkv=True, gate_mode="lowrank", gate_rank=2, gate_init="mix5")
+    dense = save_chain == "dense"
+    save_chain = bool(save_chain)
+    kw = dict(gate_mode="dense", use_k3=False, gate_init="and") if dense else dict(gate_mode="lowrank", gate_rank=2, gate_init="mix5")
+    m = EdgewiseMSA(D, Hh, attn_drop=p, n_views=V, share_qkv=True, **kw)
     with torch.no_grad():
-        for prm in m.parameters():
+        for n_, prm in m.named_parameters():
             prm.add_(0.1 * torch.randn_like(prm))
+            if n_.endswith("conv2.bias"):
+                prm.copy_(0.7 * torch.randn_like(prm))
     params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
     x = torch.randn(B, N, D)
     w = torch.randn(B, N, D)

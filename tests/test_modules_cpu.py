@@ -101,7 +101,7 @@ def test_attention_dropout_in_training_raises_where_the_kernels_do_not_carry_it(
     it (tests/test_gpu_dropout.py); configurations that run the generic path refuse it instead of silently training a different
     model -- e.g. the dense gate head."""
     from mop_amd.nn import EdgewiseMSA
-    m = EdgewiseMSA(64, 4, attn_drop=0.1, gate_mode="dense").train()
+    m = EdgewiseMSA(64, 4, attn_drop=0.1, gate_mode="dense", use_k3=True).train()
     with pytest.raises(NotImplementedError, match="attn_drop"):
         m(torch.randn(1, 8, 64))
 
