@@ -50,12 +50,18 @@ class MSA(nn.Module):
         self.proj = TokenLinear(dim, dim, bias=False)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """`residual` (default None = reference behaviour): returns `residual + attn(x)`, the add folded into proj's GEMM"""
         B, N, D = x.shape
         pdrop = float(self.attn_drop.p) if self.training else 0.0      # self.attn_drop(A) (:62), inside the kernels
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
         y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p=pdrop)
-        return self.proj_drop(self.proj(y))
+        if residual is None:
+            return self.proj_drop(self.proj(y))
+        if y.is_cuda and y.dtype == residual.dtype == self.proj.weight.dtype and not torch.is_autocast_enabled() \
+                and not (self.training and self.proj_drop.p > 0):
+            return residual_linear(residual, y, self.proj.weight)
+        return residual + self.proj_drop(self.proj(y))
 
 
 class MLP(nn.Module):
@@ -89,8 +95,16 @@ class Block(nn.Module):
         self.dp2 = DropPath(drop_path)
 
     def forward(self, x):
-        x = x + self.dp1(self.attn(self.ln1(x)))
-        return x + self.dp2(self.mlp(self.ln2(x)))
+        idle = lambda dp: not (self.training and dp.drop_prob > 0.0)
+        if not (x.is_cuda and idle(self.dp1) and idle(self.dp2) and ops.layernorm_supported(x, self.ln1.weight)):
+            x = x + self.dp1(self.attn(self.ln1(x)))
+            return x + self.dp2(self.mlp(self.ln2(x)))
+        # LayerNorm prologue + residual epilogue (mopk_layernorm_*, the add in the projection GEMM), as in BlockEdgewise
+        odt = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else x.dtype
+        xr, h = ops.layernorm_residual(x, self.ln1.weight, self.ln1.bias, self.ln1.eps, odt)
+        x = self.attn(h, residual=xr)
+        xr, h = ops.layernorm_residual(x, self.ln2.weight, self.ln2.bias, self.ln2.eps, odt)
+        return self.mlp(h, residual=xr)
 
 
 class ViTEncoder(nn.Module):
