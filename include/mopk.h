@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 113 /* 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
+#define MOPK_VERSION 114 /* 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -141,6 +141,11 @@ typedef struct MopkEdgewiseArgs {
     const MopkEdgewiseExt *ext; /* host pointer; NULL = low-rank head without lens bank (the only form the fused path takes) */
     float dropout_p;         /* attn_drop on the mixed attention weights (:552), fused path only; see MopkSdpaArgs.dropout_p */
     uint64_t dropout_seed;
+    /* Optional attention mask, 1 = keep (generic path only).  EXTENSION: the reference's masked EdgewiseMSA is NaN for any blocking
+     * mask (-inf scores enter the feature stack, :504-506 -> :518-546).  Here the mask acts on the probabilities only -- the per-view
+     * softmaxes (:507) and the final one (:549-551); gate features see the unmasked scores.  Every row must keep at least one key. */
+    const uint8_t *mask;
+    int64_t mask_sb, mask_sh, mask_si;
 } MopkEdgewiseArgs;
 
 size_t mopk_edgewise_saved_bytes(const MopkEdgewiseArgs *a);

@@ -51,6 +51,7 @@ class EdgewiseArgs(C.Structure):
         ("dWr", _fp), ("dbr", _fp), ("dWc", _fp), ("dbc", _fp), ("dlogit_part", _fp),
         ("ext", C.POINTER(EdgewiseExt)),
         ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
+        ("mask", _fp), ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_si", C.c_int64),
     ]
 
 

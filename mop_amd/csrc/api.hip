@@ -35,6 +35,7 @@ static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
     if (a->B <= 0 || a->H <= 0 || a->N <= 0 || a->dk <= 0 || a->V < 2 || a->r < 1) return MOPK_ERR_BAD_SHAPE;
     if (a->io_dtype != MOPK_F32 && a->io_dtype != MOPK_BF16) return MOPK_ERR_BAD_ARG;
     if (a->precision != MOPK_PREC_FP32 && a->precision != MOPK_PREC_BF16) return MOPK_ERR_BAD_ARG;
+    if (a->mask && a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;      // attention mask: generic path only
     const MopkEdgewiseExt *x = a->ext;
     const bool dense = x && x->gate_mode == 1;
     if (x) {

@@ -817,6 +817,7 @@ static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
     if (a->precision != MOPK_PREC_BF16) return 0;             // fused kernels are the bf16-MFMA path
+    if (a->mask) return 0;                                    // attention mask (extension): generic path
     if (a->ext && a->ext->n_lens > 0) return 0;               // lens banks: generic path
     if (a->ext && a->ext->gate_mode != 0) {                   // dense gate head: forward only, without the 3x3 convolution, full record
         if (a->ext->gate_mode != 1 || a->ext->use_k3 || !a->save_for_backward) return 0;

@@ -158,20 +158,29 @@ __global__ void ew_prep_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s) {
 }
 
 // one wave per row: out = softmax(in), rowmean(in)
-__global__ void softmax_rows_kernel(const float *in, float *out, float *rowmean, int64_t rows, int N, int LD) {
+// optional attention mask (1 = keep) of row (bh, i): extension, acts on the probabilities only (see MopkEdgewiseArgs.mask)
+struct RowMask { const uint8_t *p; int64_t sb, sh, si; int H, N; };
+__device__ __forceinline__ const uint8_t *mask_row(const RowMask &m, int64_t bhi) {      // bhi = bh * N + i
+    if (!m.p) return nullptr;
+    const int64_t bh = bhi / m.N, i = bhi % m.N;
+    return m.p + (bh / m.H) * m.sb + (bh % m.H) * m.sh + i * m.si;
+}
+// rows = V * BH * N rows of S (view-major); the row mean (a gate feature) is of the unmasked scores
+__global__ void softmax_rows_kernel(const float *in, float *out, float *rowmean, int64_t rows, int N, int LD, RowMask m, int64_t rows1) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float *p = in + row * LD;
+    const uint8_t *mk = mask_row(m, row % rows1);
     float mx = -INFINITY, sm = 0.f;
-    for (int j = lane; j < N; j += 64) { float v = p[j]; mx = fmaxf(mx, v); sm += v; }
+    for (int j = lane; j < N; j += 64) { float v = p[j]; if (!mk || mk[j]) mx = fmaxf(mx, v); sm += v; }
     mx = wave_max(mx); sm = wave_sum(sm);
     float den = 0.f;
-    for (int j = lane; j < N; j += 64) den += expf(p[j] - mx);
+    for (int j = lane; j < N; j += 64) den += (!mk || mk[j]) ? expf(p[j] - mx) : 0.f;
     den = wave_sum(den);
     const float inv = 1.f / den;
     float *o = out + row * LD;
-    for (int j = lane; j < N; j += 64) o[j] = expf(p[j] - mx) * inv;
+    for (int j = lane; j < N; j += 64) o[j] = (!mk || mk[j]) ? expf(p[j] - mx) * inv : 0.f;
     if (lane == 0) rowmean[row] = sm / N;
 }
 // thread per column
@@ -354,13 +363,16 @@ __global__ void mix_fwd_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s) {
     const int64_t vstride = d.BH * (int64_t)d.N * d.LD;
     const float nb = a.beta_not / (float)max(1, d.V - 1);
     float *P = s.P + row * d.LD;
+    const RowMask rmk{a.mask, a.mask_sb, a.mask_sh, a.mask_si, a.H, d.N};
+    const uint8_t *mk = mask_row(rmk, row);
     float mx = -INFINITY;
     for (int j = lane; j < d.N; j += 64) {
         float sv[MAXV], O, lse, G[4];
         view_stats(s.S, vstride, row * d.LD + j, d.V, sv, O, lse);
         edge_gates(G, d, s, rg, gb, row, j);
         const float cr = s.Cr[row * d.LD + j];
-        const float sm = sv[0] + G[0] * O + G[1] * (lse - sv[0]) - G[2] * (nb * O) + G[3] * cr;
+        float sm = sv[0] + G[0] * O + G[1] * (lse - sv[0]) - G[2] * (nb * O) + G[3] * cr;
+        if (mk && !mk[j]) sm = -INFINITY;                               // re-mask :549-550 (extension: see MopkEdgewiseArgs.mask)
         P[j] = sm; mx = fmaxf(mx, sm);
     }
     mx = wave_max(mx);
@@ -862,7 +874,8 @@ static int ew_generic_fwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
         RET_IF(bgemm(g, mf, st));
     }
     const int64_t rowsV = (int64_t)V * d.BH * N, rows1 = d.BH * N;
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rowsV + 3) / 4), dim3(256), 0, st, s.S, s.A, s.rS, rowsV, N, LD);  // :507
+    const RowMask rm{a->mask, a->mask_sb, a->mask_sh, a->mask_si, a->H, N};
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rowsV + 3) / 4), dim3(256), 0, st, s.S, s.A, s.rS, rowsV, N, LD, rm, rows1);  // :504-507
     hipLaunchKernelGGL(colmean_kernel, dim3((N + 255) / 256, V * BHi), dim3(256), 0, st, s.S, s.cS, N, LD);
     MOPK_CHECK_LAUNCH();
     // chains                                                            :508-515

@@ -164,10 +164,12 @@ class EdgewiseMSA(nn.Module):
         self.chain_value_logit = nn.Parameter(torch.tensor(-2.0))
 
     def _check_supported(self, attn_mask):
-        if attn_mask is not None:
-            raise NotImplementedError(
-                "EdgewiseMSA with attn_mask: the reference returns NaN for any blocking mask "
-                "(SURVEY.md 8a note); not supported by the kernels")
+        # attn_mask: an EXTENSION.  The reference fills the scores with -inf before they enter the feature stack (:504-506 feed :518-546),
+        # so its output is NaN for any blocking mask (SURVEY.md 8a note).  Here the mask (0 = blocked) acts on the attention
+        # probabilities only -- the per-view softmaxes and the final one -- while the gate features see the unmasked scores; it runs on
+        # the generic path, and every query must keep at least one key (a causal mask does).
+        if attn_mask is not None and self.training and self.attn_drop.p > 0:
+            raise NotImplementedError("attn_drop > 0 in training mode with attn_mask: the generic path does not carry dropout")
         if self.use_lens_bank and self.lens_kernel_size != 3:
             raise ValueError("lens_kernel_size must be 3: with padding = dilation any other size changes the plane size and "
                              "the reference's feature stack (:534) cannot be built")
@@ -229,7 +231,7 @@ class EdgewiseMSA(nn.Module):
             qkv = F.linear(x, w).view(B, N, V, 3, H, dk)
             sqk = torch.full((V, H, dk), inv, device=x.device, dtype=torch.float32)
             vs0 = vsL = torch.ones(H, dk, device=x.device, dtype=torch.float32)
-        if not dense and not self.use_lens_bank:
+        if not dense and not self.use_lens_bank and attn_mask is None:
             y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,
                                           eh.col_proj.weight.squeeze(-1), eh.col_proj.bias,
                                           self.chain_value_logit, float(self.beta_not), n_s,
@@ -246,7 +248,8 @@ class EdgewiseMSA(nn.Module):
             head = (eh.row_proj.weight.squeeze(-1), eh.row_proj.bias, eh.col_proj.weight.squeeze(-1), eh.col_proj.bias)
             W3 = b3 = None
         y = ops.edgewise_general_core(qkv, sqk, vs0, vsL, self.chain_value_logit, head, float(self.beta_not), n_s, var,
-                                      W3=W3, b3=b3, lens_w=lens_w, dropout_p=float(self.attn_drop.p) if self.training else 0.0)
+                                      W3=W3, b3=b3, lens_w=lens_w, dropout_p=float(self.attn_drop.p) if self.training else 0.0,
+                                      attn_mask=attn_mask)
         return self._project(y, residual)
 
 

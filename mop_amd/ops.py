@@ -279,7 +279,8 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
     (unused ones are passed as empty tensors)."""
 
     @staticmethod
-    def forward(ctx, qkv, sqk, vs0, vsL, logit, h0, h1, h2, h3, W3, b3, lens_w, beta_not, V, prec, var, wants_grad=True, drop=(0.0, 0)):
+    def forward(ctx, qkv, sqk, vs0, vsL, logit, h0, h1, h2, h3, W3, b3, lens_w, beta_not, V, prec, var, wants_grad=True, drop=(0.0, 0),
+                mask=None):
         _require_gpu(qkv, "EdgewiseMSA")
         lib = L.lib()
         B, N, Vq, _, H, dk = qkv.shape
@@ -304,7 +305,9 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
         # dense head without the 3x3 convolution / lens bank: the fused kernels evaluate it inside their mix loops (the backward
         # keeps dW1[k][:] and db1[k] in one 16-slot row, i.e. covers V <= 6)
-        if var.dense and not var.use_k3 and not var.lens_dilations and _PATH != L.PATH_GENERIC and (not wants_grad or V <= 6):
+        m8, ms = _mask_u8(mask, B, H, N, dev)
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        if var.dense and not var.use_k3 and not var.lens_dilations and m8 is None and _PATH != L.PATH_GENERIC and (not wants_grad or V <= 6):
             a.path, a.save_for_backward = L.PATH_FUSED, 1
             if not lib.mopk_edgewise_fused_supported(C.byref(a)):
                 a.path, a.save_for_backward = L.PATH_GENERIC, 0
@@ -322,7 +325,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         ctx.save_for_backward(qkv, saved, *f.values())
         ctx.keys = list(f.keys())
         ctx.meta = (beta_not, V, prec, var, int(a.r))
-        ctx.fwd_path, ctx.drop = int(a.path), drop
+        ctx.fwd_path, ctx.drop, ctx.mask = int(a.path), drop, (m8, ms)
         return y.view(B, N, H * dk)
 
     @staticmethod
@@ -342,6 +345,7 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
         a.io_dtype, a.precision, a.path, a.beta_not = _io_dtype(qkv), prec, path, float(beta_not)
         a.save_for_backward = int(path == L.PATH_FUSED)
         a.dropout_p, a.dropout_seed = float(ctx.drop[0]), int(ctx.drop[1])
+        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(ctx.mask[0]), ctx.mask[1]
         _ew_views(a, qkv, "")
         a.sqk, a.vs0, a.vsL, a.chain_logit = f["sqk"].data_ptr(), f["vs0"].data_ptr(), f["vsL"].data_ptr(), f["logit"].data_ptr()
         a.y = L.View4(dy.data_ptr(), N * H * dk, dk, H * dk)
@@ -373,12 +377,12 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
             rc = lib.mopk_edgewise_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_bwd")
         return (dqkv, dsqk.sum(0), dvs0.sum(0), dvsL.sum(0), dlg.sum().reshape(()), g["h0"], g["h1"], g["h2"], g["h3"],
-                g["W3"], g["b3"], g["lens_w"], None, None, None, None, None, None)
+                g["W3"], g["b3"], g["lens_w"], None, None, None, None, None, None, None)
 
 
 def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float, n_views: int, variant: EdgewiseVariant,
                           W3=None, b3=None, lens_w=None, precision: Optional[int] = None, dropout_p: float = 0.0,
-                          seed: Optional[int] = None):
+                          seed: Optional[int] = None, attn_mask=None):
     """EdgewiseMSA core for the dense gate head and/or the S lens bank.  head = (Wr, br, Wc, bc) for the low-rank head
     with C = 2V+2+L*V input channels, or (W1 (16,C), b1, W2 (4,16), b2) for the dense head; W3/b3 with use_k3;
     lens_w (L,V,3,3).  qkv as in edgewise_lowrank_core."""
@@ -389,7 +393,7 @@ def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float
     wants_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad
                                                  for t in (qkv, sqk, vs0, vsL, chain_logit, *head, W3, b3, lens_w))
     return _EdgewiseGeneralFn.apply(qkv, sqk, vs0, vsL, chain_logit, *head, e if W3 is None else W3, e if b3 is None else b3,
-                                    e if lens_w is None else lens_w, beta_not, n_views, prec, variant, wants_grad, drop)
+                                    e if lens_w is None else lens_w, beta_not, n_views, prec, variant, wants_grad, drop, attn_mask)
 
 
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,

@@ -141,7 +141,7 @@ def dense_head_bwd(dZ, c, hp):
 # ----------------------------------------------------------------------------
 # attention core: everything between the qkv projection and the out projection
 # ----------------------------------------------------------------------------
-def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, lens=None, drop=None):
+def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, lens=None, drop=None, blocked=None):
     """EdgewiseMSA.forward :500-562 for per-view queries/keys.
 
     qv, kv : (V,B,H,N,dk)  per-view q_i, k_i   (:461-470)
@@ -149,12 +149,22 @@ def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, 
     Wr, Wc : (4r, C) with C = 2V+2 ; br, bc : (4r,)
     dense  : None (low-rank head, Wr.. used) or dict W1,b1,[W3,b3],W2,b2 (dense head, Wr.. ignored)
     lens   : None or (lens_w (L,V,3,3), dils) -- extra feature channels l*V+v after [S, S^T, Cr, Cl]  (:533)
+    blocked: None or bool (.., N, N), True = masked edge.  EXTENSION, not reference behaviour: the reference fills the scores with
+             -inf before they enter the feature stack (:504-506 feed :518-546), which makes every output NaN for any blocking mask
+             (SURVEY.md 8a note).  Here the mask acts on the attention probabilities only -- the per-view softmaxes (:507) and the final
+             one (:549-551) -- while the gate features (scores, their means, lse, chain logs) see the unmasked finite scores.
     returns y (B,H,N,dk) and a cache for core_bwd.
     """
     V, B, H, N, dk = qv.shape
     scale = 1.0 / math.sqrt(dk)
     S = np.matmul(qv, np.swapaxes(kv, -1, -2)) * scale          # :500-503  (V,B,H,N,N)
-    A = _softmax(S, -1)                                           # :507
+    if blocked is not None:
+        blocked = np.broadcast_to(np.asarray(blocked, dtype=bool), S.shape[1:])
+        Sm = np.where(blocked[None], -np.inf, S)
+        e = np.where(blocked[None], 0.0, np.exp(Sm - Sm.max(-1, keepdims=True)))
+        A = e / e.sum(-1, keepdims=True)                          # :504-507
+    else:
+        A = _softmax(S, -1)                                       # :507
     T = [A[0]]                                                    # :508-512 prefix products
     for i in range(1, V):
         T.append(np.matmul(T[-1], A[i]))
@@ -200,7 +210,12 @@ def core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, chain_logit, dense=None, 
     nb = beta_not / max(1, V - 1)                                 # :542,546
     Smix = S0 + G[:, :, 0] * O + G[:, :, 1] * (lse - S0) - G[:, :, 2] * (nb * O) \
         + G[:, :, 3] * Cr                                         # :543-547
-    P = _softmax(Smix, -1)                                        # :551
+    if blocked is not None:
+        Sx = np.where(blocked, -np.inf, Smix)                     # :549-550
+        e = np.where(blocked, 0.0, np.exp(Sx - Sx.max(-1, keepdims=True)))
+        P = e / e.sum(-1, keepdims=True)
+    else:
+        P = _softmax(Smix, -1)                                    # :551
     Pd = P if drop is None else P * drop                          # :552 attn_drop with the mask made explicit: drop = keep / (1 - p)
     y_base = np.matmul(Pd, v0)                                    # :554
     t = [None] * V                                                # :557-560 value transport
@@ -361,7 +376,7 @@ def _head_params(params):
 
 
 def module_fwd(x, params: Dict[str, np.ndarray], heads: int, n_views: int, share_qkv: bool,
-               beta_not: float = 0.5, lens_dilations=None, lens_qk=None, drop=None):
+               beta_not: float = 0.5, lens_dilations=None, lens_qk=None, drop=None, attn_mask=None):
     """lens_dilations: dilations of the S lens bank (params lens_bank.{l}.weight) or None;
     lens_qk: None or (dilations, causal) for the Q/K lens bank (params q_lens.{l}.weight, k_lens.{l}.weight);
     drop: None or the attn_drop multiplier keep / (1 - p) per edge, (B,H,N,N) (:552 with the mask made explicit)."""
@@ -402,7 +417,9 @@ def module_fwd(x, params: Dict[str, np.ndarray], heads: int, n_views: int, share
     lens = None
     if lens_dilations is not None:
         lens = (np.stack([params[f"lens_bank.{l}.weight"][:, 0] for l in range(len(lens_dilations))]), tuple(lens_dilations))
-    y, cache = core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, params["chain_value_logit"], dense=dense, lens=lens, drop=drop)
+    blocked = None if attn_mask is None else (np.asarray(attn_mask) == 0)       # reference convention: 0 = blocked (:504)
+    y, cache = core_fwd(qv, kv, v0, vL, Wr, br, Wc, bc, beta_not, params["chain_value_logit"], dense=dense, lens=lens, drop=drop,
+                        blocked=blocked)
     ycat = np.transpose(y, (0, 2, 1, 3)).reshape(B, N, D)         # :563
     out = ycat @ params["proj.weight"].T                          # :564
     cache.update(x=x, ycat=ycat, share=share_qkv, H=H, V=V, params=params, lens_qk=lens_qk, qk_ctx=qk_ctx,

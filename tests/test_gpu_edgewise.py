@@ -542,6 +542,54 @@ def test_fused_dense_head_forward_vs_reference_fixture():
     assert max_abs(y.cpu().numpy(), d["y"]) <= TOL_BF16
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("variant", ["lowrank", "dense", "dense_k3"])
+@pytest.mark.parametrize("mask_kind", ["causal", "random"])
+def test_masked_edgewise_extension_vs_oracle(variant, mask_kind, prec):
+    """attn_mask on EdgewiseMSA: the reference is NaN there (SURVEY.md 8a note); the documented extension (mask on the probabilities
+    only, gate features from the unmasked scores; generic path) against the float64 oracle, whose masked backward is pinned by finite
+    differences in tests/test_oracle_golden.py."""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import EdgewiseMSA
+    B, N, D, H, V = 2, 37, 64, 2, 3
+    kw = dict(gate_mode="lowrank", gate_rank=2, gate_init="mix5") if variant == "lowrank" else \
+        dict(gate_mode="dense", use_k3=variant == "dense_k3", gate_init="and")
+    torch.manual_seed(41)
+    m = EdgewiseMSA(D, H, n_views=V, share_qkv=True, **kw)
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("_scale"):
+                p.add_(0.1 * torch.randn_like(p))
+            elif n_.endswith("conv2.bias"):
+                p.copy_(0.5 * torch.randn_like(p))
+        m.chain_value_logit.fill_(-0.5)
+    if mask_kind == "causal":
+        mask = torch.ones(N, N).tril_()
+    else:
+        mask = (torch.rand(B, 1, N, N) > 0.4).float()
+        mask[..., torch.arange(N), torch.arange(N)] = 1.0            # every query keeps at least one key
+    params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+    x = torch.randn(B, N, D).numpy()
+    w = torch.randn(B, N, D).numpy()
+    out, cache = oe.module_fwd(x.astype(np.float64), params, H, V, True, 0.5, attn_mask=mask.numpy())
+    dx_ref, g_ref = oe.module_bwd(w.astype(np.float64), cache)
+    mop_amd.set_precision(prec)
+    try:
+        y, dx, grads = run_fwd_bwd(m.cuda().eval(), x, w, attn_mask=mask.cuda())
+        assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_GENERIC and ops.LAST_PATH["edgewise_bwd"] == _lib.PATH_GENERIC
+    finally:
+        mop_amd.set_precision("auto")
+    assert np.isfinite(y).all() and np.isfinite(dx).all()
+    tol, gtol = (1e-4, 1e-3) if prec == "fp32" else (TOL_BF16, GTOL_BF16)
+    assert max_abs(y, out) <= tol * max(1.0, float(np.abs(out).max())), f"y {max_abs(y, out):.3e}"
+    assert rel_err(dx, dx_ref) <= gtol, f"dx {rel_err(dx, dx_ref):.3e}"
+    noise = oracle_bf16_noise(lambda xx, pp, *a_: oe.module_fwd(xx, pp, *a_, attn_mask=mask.numpy()), oe.module_bwd, x, w, params,
+                              H, V, True, 0.5) if prec == "bf16" else None
+    check_grads(grads, g_ref, gtol, floor=1e-3, d=noise)
+
+
 def test_fused_lowrank_batch_of_three_at_full_size_vs_oracle():
     """B = 3 images at the north-star layer shape (N = 197, D = 384, 6 heads, 5 views, r = 4), fused bf16 kernels vs the float64 oracle:
     the reference fixture at this shape is B = 1, so batch striding of every launch (saved records, hand-off regions, partials) is

@@ -88,8 +88,10 @@ def test_unified_switch():
 def test_unsupported_variants_raise_instead_of_falling_back():
     from mop_amd.nn import EdgewiseMSA
     x = torch.randn(1, 8, 64)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # masked Edgewise (an extension, generic path) -- still never on the CPU
         EdgewiseMSA(64, 4, gate_mode="lowrank", share_qkv=True)(x, attn_mask=torch.ones(8, 8))
+    with pytest.raises(NotImplementedError, match="attn_mask"):
+        EdgewiseMSA(64, 4, attn_drop=0.1, gate_mode="lowrank", share_qkv=True).train()(x, attn_mask=torch.ones(8, 8))
     with pytest.raises(ValueError):      # reference: torch.stack fails for lens_kernel_size != 3 (:534)
         EdgewiseMSA(64, 4, gate_mode="lowrank", share_qkv=True, use_lens_bank=True, lens_kernel_size=5)(x)
     with pytest.raises(RuntimeError, match="no CPU fallback"):   # dense head is built, but never on the CPU: no fallback path
