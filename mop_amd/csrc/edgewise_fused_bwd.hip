@@ -892,6 +892,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
                 // ---- features and first layer: z1[e][k] = b1[k] + sum_c W1[k][c] f_c[e]
                 f32x16 z1[E];                                       // z1[e][k]: pre-activation (later dz1) of hidden unit k for edge e; k may be a runtime index
+                f32x16 F[E];                                        // F[e][c]: feature channel c of edge e (C <= 14), kept for the second pass
+#pragma unroll
+                for (int e = 0; e < E; ++e) F[e] = zero16();
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
@@ -902,6 +905,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         for (int e = 0; e < E; ++e) z1[e][4 * k4 + kk] = bb[kk];
                 }
                 auto accum = [&](int c, const float (&f)[E]) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) F[e][c] = f[e];
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
@@ -978,11 +983,11 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         pb[m] = wave_sum(sacc); }
                     if (lane < 4) wme[16 * 16 + 16 * 4 + lane] += lane == 0 ? pb[0] : lane == 1 ? pb[1] : lane == 2 ? pb[2] : pb[3];
                 }
+                f32x16 hq[E];                                       // hq[e][k] = gelu(z1[e][k]): operand of the dW2 rows below
 #pragma nounroll
                 for (int k = 0; k < 16; ++k) {
                     const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
                     const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
-                    float pw2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         const float u = z1[e][k];
@@ -992,21 +997,24 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                         const float gp = sg + hv * (1.f - sg) * 1.5957691216057308f * (1.f + 0.134145f * u * u);     // d gelu_tanh / du
                         float dh = 0.f;
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) { dh = fmaf(ww[m], dzz[m][e], dh); pw2[m] = fmaf(dzz[m][e], hv, pw2[m]); }
+                        for (int m = 0; m < 4; ++m) dh = fmaf(ww[m], dzz[m][e], dh);
                         z1[e][k] = dh * gp;                          // dz1
-                    }
-                    {   // dW2^T row k: four values; two halving steps, then four plain ones
-                        const bool b0 = lane & 1, b1 = lane & 2;
-                        float a2[2];
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) a2[i] = (b0 ? pw2[2 + i] : pw2[i]) + xchg(b0 ? pw2[i] : pw2[2 + i], 1);
-                        float sred = (b1 ? a2[1] : a2[0]) + xchg(b1 ? a2[0] : a2[1], 2);
-                        sred += xchg(sred, 4); sred += xchg(sred, 8); sred += __shfl_xor(sred, 16, 64); sred += __shfl_xor(sred, 32, 64);
-                        if (lane < 4) wme[16 * 16 + 4 * k + (((lane & 1) << 1) | ((lane & 2) >> 1))] += sred;
+                        hq[e][k] = hv;
                     }
                 }
-                // ---- second pass over the channels: the feature group is recomputed (matrix core), dW1[:, c] = sum_e dz1[:, e] f_c[e]
-                //      reduced over the wave (16 hidden units = one butterfly), df_c = sum_k W1[k][c] dz1[k] -> hand-off slabs
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {                         // dW2[m][:] = sum_e dz2[m][e] h[:][e]: one 16-wide butterfly per gate
+                    float row[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { float sacc = 0.f;
+#pragma unroll
+                        for (int e = 0; e < E; ++e) sacc = fmaf(dzz[m][e], hq[e][k], sacc);
+                        row[k] = sacc; }
+                    const float rs = reduce16(row);
+                    if ((lane >> 4) == 0) wme[16 * 16 + 4 * ridx + m] += rs;      // table [k][m]
+                }
+                // ---- second pass over the channels: dW1[:, c] = sum_e dz1[:, e] f_c[e] reduced over the wave (16 hidden units = one
+                //      butterfly), df_c = sum_k W1[k][c] dz1[k] -> hand-off slabs
                 float g1q[E], gAq[E], lseq[E];
 #pragma unroll
                 for (int e = 0; e < E; ++e) { g1q[e] = G[1][e]; gAq[e] = fmaf(-nb, G[2][e], G[0][e]); lseq[e] = Lq[e] + S0q[e]; }
@@ -1022,17 +1030,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 }
                 for (int c = 0; c < C; ++c) {
                     float f[E];
-                    if (c < 2 * V) {
-                        bf16x8 qe[KS];
-                        const int v = c < V ? c : c - V;
-                        if (c < V) scale_frag(qe, qraw_t, sqk + v * DK); else scale_frag(qe, kraw_t, sqk + v * DK);
-                        const f32x16 Sv = c < V ? s_tile(qe, t) : st_tile(qe, t);
 #pragma unroll
-                        for (int e = 0; e < E; ++e) f[e] = Sv[g0 + e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) f[e] = c == 2 * V ? Crq[e] : Clq[e];
-                    }
+                    for (int e = 0; e < E; ++e) f[e] = F[e][c];
                     float row[16], df[E];
 #pragma unroll
                     for (int e = 0; e < E; ++e) df[e] = 0.f;
