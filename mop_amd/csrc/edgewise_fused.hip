@@ -786,7 +786,8 @@ int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     if (dense) dw = FusedDenseW{a->ext->W1, a->ext->b1, a->ext->W2, a->ext->b2};
 #define MOPK_LAUNCH(IOT_, SAVE_, HEAD_) do {                                                                      \
         auto kfn = ew_fused_fwd_kernel<NT, DK, IOT_, SAVE_, HEAD_>;                                               \
-        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
+        static int lds_set = 0;      /* per instantiation and per process: the attribute is sticky (and may not be set during stream capture) */ \
+        if (lds_set < lds) { if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; lds_set = lds; } \
         hipLaunchKernelGGL(kfn, grid, block, lds, st, *a, dw);                                                    \
     } while (0)
     if (dense) { if (a->io_dtype == MOPK_BF16) MOPK_LAUNCH(unsigned short, true, 1); else MOPK_LAUNCH(float, true, 1); }

@@ -1562,7 +1562,8 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     const dim3 block(NT * 64);
 #define MOPK_LAUNCH_H(IOT_, PH_, GRID_, HEAD_) do {                                                               \
         auto kfn = ew_fused_bwd_kernel<NT, DK, IOT_, PH_, HEAD_>;                                                 \
-        if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; \
+        static int lds_set = 0;      /* per instantiation and per process: the attribute is sticky (and may not be set during stream capture) */ \
+        if (lds_set < lds) { if (hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return MOPK_ERR_LAUNCH; lds_set = lds; } \
         hipLaunchKernelGGL(kfn, dim3(GRID_), block, lds, st, *a, W, dw);                                          \
     } while (0)
 #define MOPK_LAUNCH(IOT_, PH_, GRID_) do { if (dense) MOPK_LAUNCH_H(IOT_, PH_, GRID_, 1); else MOPK_LAUNCH_H(IOT_, PH_, GRID_, 0); } while (0)

@@ -614,4 +614,3 @@ def test_fused_lowrank_batch_of_three_at_full_size_vs_oracle():
         assert rel_err(dx[b], dx_ref[b]) <= 3e-2, f"dx[{b}] {rel_err(dx[b], dx_ref[b]):.3e}"
     noise = oracle_bf16_noise(oe.module_fwd, oe.module_bwd, x, w, params, H, V, True, 0.5, samples=2)
     check_grads(grads, g_ref, GTOL_BF16, d=noise)
-
