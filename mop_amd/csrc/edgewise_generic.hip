@@ -101,7 +101,7 @@ struct EwWork {
     float *drL, *dcL;              // low-rank head: gradients of the lens planes' row / col means (L*V,BH,N)
     float *part;                   // [PR_BLOCKS][PR_MAXOUT] partial sums of the weight-gradient reductions
 };
-constexpr int PR_BLOCKS = 512, PR_MAXOUT = HID * (HID * 9 + 1);   // largest reduction: dW3 | db3
+constexpr int PR_BLOCKS = 768, PR_MAXOUT = HID * (HID * 9 + 1);   // largest reduction: dW3 | db3
 static EwWork ew_carve_work(void *p, const EwDims &d, size_t *total) {
     Carver c(p);
     EwWork w;
@@ -730,51 +730,136 @@ struct LdLast1 {           // input of conv2: X3 (use_k3) or gelu(X1); then the 
         return k3 ? x : gelu_tanh(x);
     }
 };
-struct LdTaps1 {           // the 3x3 neighbourhood of H2: channel c*9 + a*3 + b -> H2_c(i+a-1, j+b-1); then the constant 1
-    const float *H2; int64_t nn; int N, LD;
-    __device__ float operator()(int b, int64_t bh, int i, int j) const {
-        if (b >= HID * 9) return 1.f;
-        const int c = b / 9, t = b % 9, ii = i + t / 3 - 1, jj = j + t % 3 - 1;
-        if (ii < 0 || ii >= N || jj < 0 || jj >= N) return 0.f;
-        return H2[c * nn + (bh * N + ii) * (int64_t)LD + jj];
+// One tile = up to PR_PS pixels of one row (b,h,i): the A planes and the B channels go to LDS, then the 16 x nB sums of products
+// run on the f32 matrix core (v_mfma_f32_16x16x4_f32: exact f32 fma chains).  Wave w takes the 4-pixel k-steps w, w+4, ... of
+// every tile, so the four waves' partials are added once at the end, in wave order (bit-reproducible).  The next tile's values
+// are fetched into registers while the matrix core works on the current one.
+constexpr int PR_PS = 64, PR_LDS = PR_PS + 4;        // pixels per tile; LDS row stride (fragment reads touch all 64 banks)
+struct PrTile { int64_t bh; int i, j0, jn; };
+__device__ inline PrTile pr_tile(const EwDims &d, int64_t tile, int pc, int strips) {
+    const int64_t row = tile / strips, bh = row / d.N;
+    const int strip = (int)(tile - row * strips), j0 = strip * pc;
+    return PrTile{bh, (int)(row - bh * d.N), j0, min(pc, d.N - j0)};
+}
+// the four waves' [a][b] accumulators -> part[block][a * nB + b]; S is reused as [wave][16][16 * NT]
+template <int NT>
+__device__ inline void pr_finish(float *S, const f32x4 (&acc)[NT], int nA, int nB, float *part) {
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        for (int r = 0; r < 4; ++r) S[(w * HID + 4 * lq + r) * (16 * NT) + 16 * t + lr] = acc[t][r];
+    __syncthreads();
+    for (int o = tid; o < nA * nB; o += 256) {
+        const int ai = o / nB, bi = o % nB;
+        float sm = 0.f;
+        for (int ww = 0; ww < 4; ++ww) sm += S[(ww * HID + ai) * (16 * NT) + bi];
+        part[(int64_t)blockIdx.x * PR_MAXOUT + o] = sm;
     }
-};
-constexpr int PR_P = 32, PR_MAXB = HID * 9 + 1, PR_PER_T = (PR_MAXOUT + 255) / 256;
+}
+constexpr int PG_NT = 2, PG_ROWS = HID + 16 * PG_NT, PG_IT = (PG_ROWS * PR_PS + 255) / 256;   // nB <= 32 (conv1: 2V+3, conv2: 17)
+static_assert(2 * MAXV + 3 <= 16 * PG_NT && HID + 1 <= 16 * PG_NT, "pair_reduce_kernel holds two 16-channel B tiles");
+static_assert(4 * HID * 16 * PG_NT <= PG_ROWS * PR_LDS, "the end-of-kernel wave reduction reuses the staging buffer");
 template <typename LA, typename LB>
-__global__ void pair_reduce_kernel(EwDims d, LA la, LB lb, int nA, int nB, float *part) {
-    __shared__ float As[HID][PR_P], Bs[PR_MAXB][PR_P];
-    const int64_t total = d.BH * d.N * d.N, tiles = (total + PR_P - 1) / PR_P;
-    const int nOut = nA * nB;
-    float acc[PR_PER_T];
-    for (int k = 0; k < PR_PER_T; ++k) acc[k] = 0.f;
-    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        for (int idx = threadIdx.x; idx < (nA + nB) * PR_P; idx += 256) {
-            const int ch = idx / PR_P, pp = idx % PR_P;
-            const int64_t pix = tile * PR_P + pp;
-            float v = 0.f;
-            if (pix < total) {
-                const int j = pix % d.N, i = (pix / d.N) % d.N;
-                const int64_t bh = pix / ((int64_t)d.N * d.N);
-                v = ch < nA ? la(ch, bh, i, j) : lb(ch - nA, bh, i, j);
-            }
-            if (ch < nA) As[ch][pp] = v; else Bs[ch - nA][pp] = v;
+__global__ __launch_bounds__(256) void pair_reduce_kernel(EwDims d, LA la, LB lb, int nA, int nB, int pc, int strips, float *part) {
+    __shared__ float S[PG_ROWS * PR_LDS];            // rows 0..15: A planes; 16..: B channels
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
+    const int nT = (nB + 15) / 16;
+    const int64_t tiles = d.BH * d.N * strips;
+    f32x4 acc[PG_NT];
+    float v[PG_IT];
+    for (int t = 0; t < PG_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < PG_ROWS * PR_LDS; idx += 256) S[idx] = 0.f;
+    auto fetch = [&](const PrTile &t) {
+#pragma unroll
+        for (int it = 0; it < PG_IT; ++it) {
+            const int idx = tid + 256 * it, ch = idx / PR_PS, pp = idx % PR_PS;
+            v[it] = 0.f;
+            if (ch < nA + nB && pp < t.jn) v[it] = ch < nA ? la(ch, t.bh, t.i, t.j0 + pp) : lb(ch - nA, t.bh, t.i, t.j0 + pp);
+        }
+    };
+    int64_t tile = blockIdx.x;
+    PrTile cur = pr_tile(d, tile < tiles ? tile : 0, pc, strips);
+    if (tile < tiles) fetch(cur);
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int it = 0; it < PG_IT; ++it) {
+            const int idx = tid + 256 * it, ch = idx / PR_PS, pp = idx % PR_PS;
+            if (ch < nA + nB) S[(ch < nA ? ch : HID + ch - nA) * PR_LDS + pp] = v[it];
         }
         __syncthreads();
-        for (int k = 0; k < PR_PER_T; ++k) {
-            const int o = threadIdx.x + 256 * k;
-            if (o < nOut) {
-                const int ai = o / nB, bi = o % nB;
-                float t = acc[k];
-                for (int pp = 0; pp < PR_P; ++pp) t = fmaf(As[ai][pp], Bs[bi][pp], t);
-                acc[k] = t;
-            }
+        const int jn = cur.jn;
+        if (tile + gridDim.x < tiles) { cur = pr_tile(d, tile + gridDim.x, pc, strips); fetch(cur); }
+        for (int k = w; 4 * k < jn; k += 4) {
+            const float av = S[lr * PR_LDS + 4 * k + lq];
+#pragma unroll
+            for (int t = 0; t < PG_NT; ++t)
+                if (t < nT) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, S[(HID + 16 * t + lr) * PR_LDS + 4 * k + lq], acc[t], 0, 0, 0);
         }
         __syncthreads();
     }
-    for (int k = 0; k < PR_PER_T; ++k) {
-        const int o = threadIdx.x + 256 * k;
-        if (o < nOut) part[(int64_t)blockIdx.x * PR_MAXOUT + o] = acc[k];
+    pr_finish<PG_NT>(S, acc, nA, nB, part);
+}
+// dW3 | db3: the 144 tap channels are shifted copies of the 16 H2 planes, so a tile stages the three H2 rows i-1, i, i+1 with a
+// one-pixel halo (16 x 3 x 66 loads instead of 144 x 64) and every B fragment is a shifted LDS read.  Same tiling, k-step
+// split and end-of-kernel wave reduction as pair_reduce_kernel; output layout part[a * 145 + c * 9 + ta * 3 + tb], 144 -> db3.
+constexpr int TR_NT = (HID * 9 + 1 + 15) / 16, TR_HW = PR_PS + 2, TR_A = 0, TR_H = HID * PR_LDS, TR_ONE = TR_H + HID * 3 * PR_LDS,
+              TR_ZERO = TR_ONE + PR_LDS, TR_STAGE = TR_ZERO + PR_LDS, TR_RED = 4 * HID * 16 * TR_NT,
+              TR_LDS = TR_STAGE > TR_RED ? TR_STAGE : TR_RED, TR_AIT = HID * PR_PS / 256, TR_HIT = (HID * 3 * TR_HW + 255) / 256;
+__global__ __launch_bounds__(256) void taps_reduce_kernel(EwDims d, const float *X3, const float *H2, int64_t nn, int pc, int strips, float *part) {
+    __shared__ float S[TR_LDS];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lq = l >> 4;
+    const int64_t tiles = d.BH * d.N * strips;
+    int boff[TR_NT];
+    f32x4 acc[TR_NT];
+    float va[TR_AIT], vh[TR_HIT];
+#pragma unroll
+    for (int t = 0; t < TR_NT; ++t) {
+        const int b = 16 * t + lr, c = b / 9, tap = b % 9;
+        boff[t] = (b < HID * 9 ? TR_H + (c * 3 + tap / 3) * PR_LDS + tap % 3 : b == HID * 9 ? TR_ONE : TR_ZERO) + lq;
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    for (int idx = tid; idx < TR_STAGE; idx += 256) S[idx] = idx >= TR_ONE && idx < TR_ZERO ? 1.f : 0.f;
+    auto fetch = [&](const PrTile &t) {
+        const float *x3 = X3 + (t.bh * d.N + t.i) * (int64_t)d.LD + t.j0, *h2 = H2 + t.bh * d.N * (int64_t)d.LD;
+#pragma unroll
+        for (int it = 0; it < TR_AIT; ++it) {
+            const int idx = tid + 256 * it, ch = idx / PR_PS, pp = idx % PR_PS;
+            va[it] = pp < t.jn ? x3[ch * nn + pp] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < TR_HIT; ++it) {
+            const int idx = tid + 256 * it, cr = idx / TR_HW, pp = idx % TR_HW, c = cr / 3, ii = t.i + cr % 3 - 1, jj = t.j0 + pp - 1;
+            vh[it] = 0.f;
+            if (cr < HID * 3 && pp < t.jn + 2 && ii >= 0 && ii < d.N && jj >= 0 && jj < d.N) vh[it] = h2[c * nn + (int64_t)ii * d.LD + jj];
+        }
+    };
+    int64_t tile = blockIdx.x;
+    PrTile cur = pr_tile(d, tile < tiles ? tile : 0, pc, strips);
+    if (tile < tiles) fetch(cur);
+    __syncthreads();
+    for (; tile < tiles; tile += gridDim.x) {
+#pragma unroll
+        for (int it = 0; it < TR_AIT; ++it) {
+            const int idx = tid + 256 * it;
+            S[TR_A + (idx / PR_PS) * PR_LDS + idx % PR_PS] = va[it];
+        }
+#pragma unroll
+        for (int it = 0; it < TR_HIT; ++it) {
+            const int idx = tid + 256 * it, cr = idx / TR_HW;
+            if (cr < HID * 3) S[TR_H + cr * PR_LDS + idx % TR_HW] = vh[it];
+        }
+        __syncthreads();
+        const int jn = cur.jn;
+        if (tile + gridDim.x < tiles) { cur = pr_tile(d, tile + gridDim.x, pc, strips); fetch(cur); }
+        for (int k = w; 4 * k < jn; k += 4) {
+            const float av = S[TR_A + lr * PR_LDS + 4 * k + lq];
+#pragma unroll
+            for (int t = 0; t < TR_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, S[boff[t] + 4 * k], acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    pr_finish<TR_NT>(S, acc, HID, HID * 9 + 1, part);
 }
 // fixed-order sum over the blocks' partials; b < nB-1 -> dW[a*(nB-1)+b], b == nB-1 -> dbias[a]
 __global__ void pair_final_kernel(const float *part, int nblk, int nA, int nB, float *dW, float *dbias) {
@@ -965,17 +1050,19 @@ static int ew_generic_bwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
         hipLaunchKernelGGL(dense_bwd_feat_kernel, pix, dim3(256), 0, st, d, w, e);
         MOPK_CHECK_LAUNCH();
         // weight gradients: all-pairs pixel reductions, partials per block then a fixed-order sum (bit-reproducible)
-        const int64_t tiles = (d.BH * N * N + PR_P - 1) / PR_P;
+        const int strips = (N + PR_PS - 1) / PR_PS, pc = ((N + strips - 1) / strips + 3) & ~3;   // N=197: 4 strips of 52
+        const int64_t tiles = d.BH * N * strips;
         const int nblk = (int)(tiles < PR_BLOCKS ? tiles : PR_BLOCKS);
-        const LdMaps mZ{w.dZ, nnv, N, LD}, mX1{w.DX1, nnv, N, LD}, mX3{w.DX3, nnv, N, LD};
+        const LdMaps mZ{w.dZ, nnv, N, LD}, mX1{w.DX1, nnv, N, LD};
         hipLaunchKernelGGL((pair_reduce_kernel<LdMaps, LdLast1>), dim3(nblk), dim3(256), 0, st, d, mZ,
-                           LdLast1{d.k3 ? s.X3 : s.X1, nnv, N, LD, d.k3}, 4, HID + 1, w.part);
+                           LdLast1{d.k3 ? s.X3 : s.X1, nnv, N, LD, d.k3}, 4, HID + 1, pc, strips, w.part);
         hipLaunchKernelGGL(pair_final_kernel, dim3((4 * (HID + 1) + 255) / 256), dim3(256), 0, st, w.part, nblk, 4, HID + 1, e.dW2, e.db2);
         if (d.k3) {
-            hipLaunchKernelGGL((pair_reduce_kernel<LdMaps, LdTaps1>), dim3(nblk), dim3(256), 0, st, d, mX3, LdTaps1{s.H2, nnv, N, LD}, HID, HID * 9 + 1, w.part);
-            hipLaunchKernelGGL(pair_final_kernel, dim3((HID * (HID * 9 + 1) + 255) / 256), dim3(256), 0, st, w.part, nblk, HID, HID * 9 + 1, e.dW3, e.db3);
+            const int nb3 = nblk < 512 ? nblk : 512;      // 133 VGPRs: two blocks per CU
+            hipLaunchKernelGGL(taps_reduce_kernel, dim3(nb3), dim3(256), 0, st, d, w.DX3, s.H2, nnv, pc, strips, w.part);
+            hipLaunchKernelGGL(pair_final_kernel, dim3((HID * (HID * 9 + 1) + 255) / 256), dim3(256), 0, st, w.part, nb3, HID, HID * 9 + 1, e.dW3, e.db3);
         }
-        hipLaunchKernelGGL((pair_reduce_kernel<LdMaps, LdFeat1>), dim3(nblk), dim3(256), 0, st, d, mX1, LdFeat1{d, s}, HID, d.C + 1, w.part);
+        hipLaunchKernelGGL((pair_reduce_kernel<LdMaps, LdFeat1>), dim3(nblk), dim3(256), 0, st, d, mX1, LdFeat1{d, s}, HID, d.C + 1, pc, strips, w.part);
         hipLaunchKernelGGL(pair_final_kernel, dim3((HID * (d.C + 1) + 255) / 256), dim3(256), 0, st, w.part, nblk, HID, d.C + 1, e.dW1, e.db1);
     } else {
         hipLaunchKernelGGL(mix_bwd_cols_kernel, dim3((N + 63) / 64, BHi), dim3(64), 0, st, *a, d, s, w);
