@@ -607,7 +607,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
             // are picked with a wave-uniform index into the accumulator vectors (register-indexed moves)
 #pragma nounroll
             for (int q4 = 0; q4 < 4; ++q4) {                          // registers 4 q4 .. 4 q4 + 3 of the tile: four edges per lane
-                float z1[16][4];
+                typedef __attribute__((ext_vector_type(2))) float f32x2;   // edge pairs: v_pk_fma_f32 does two edges per issue
+                f32x2 z1[16][2];
 #pragma unroll
                 for (int k4 = 0; k4 < 4; ++k4) {
                     const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
@@ -615,9 +616,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = bb[kk];
+                        for (int e = 0; e < 2; ++e) z1[4 * k4 + kk][e] = f32x2{bb[kk], bb[kk]};
                 }
-                auto accum = [&](int c, const float (&f)[4]) {         // z1 += W1[:, c] (x) f
+                auto accum = [&](int c, const f32x16 &F) {             // z1 += W1[:, c] (x) f, f = registers 4 q4 .. 4 q4 + 3 of F
+                    const f32x2 f[2] = {f32x2{F[4 * q4], F[4 * q4 + 1]}, f32x2{F[4 * q4 + 2], F[4 * q4 + 3]}};
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 wv = *(const float4 *)&Wsm[c * 16 + 4 * k4];
@@ -625,52 +627,52 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) z1[4 * k4 + kk][e] = fmaf(ww[kk], f[e], z1[4 * k4 + kk][e]);
+                            for (int e = 0; e < 2; ++e)
+                                z1[4 * k4 + kk][e] = __builtin_elementwise_fma(f32x2{ww[kk], ww[kk]}, f[e], z1[4 * k4 + kk][e]);
                     }
                 };
                 {
                     bf16x8 qe[KS];
                     for (int v = 0; v < V; ++v) {
                         scale_qe(qe, qraw, v);
-                        const f32x16 Sv = s_tile(qe, t);
-                        { const float f[4] = {Sv[4 * q4], Sv[4 * q4 + 1], Sv[4 * q4 + 2], Sv[4 * q4 + 3]}; accum(v, f); }
+                        accum(v, s_tile(qe, t));
                         scale_qe(qe, kraw, v);
-                        const f32x16 Tv = st_tile(qe, t);
-                        { const float f[4] = {Tv[4 * q4], Tv[4 * q4 + 1], Tv[4 * q4 + 2], Tv[4 * q4 + 3]}; accum(V + v, f); }
+                        accum(V + v, st_tile(qe, t));
                     }
                 }
-                { const float f[4] = {Crv[4 * q4], Crv[4 * q4 + 1], Crv[4 * q4 + 2], Crv[4 * q4 + 3]}; accum(2 * V, f); }
-                { const float f[4] = {Clv[4 * q4], Clv[4 * q4 + 1], Clv[4 * q4 + 2], Clv[4 * q4 + 3]}; accum(2 * V + 1, f); }
-                float zz[4][4];
+                accum(2 * V, Crv);
+                accum(2 * V + 1, Clv);
+                f32x2 zz[4][2];
                 {
                     const float4 bv = *(const float4 *)&Wsm[384];
                     const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) zz[m][e] = bb[m];
+                        for (int e = 0; e < 2; ++e) zz[m][e] = f32x2{bb[m], bb[m]};
                 }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const float4 wv = *(const float4 *)&Wsm[320 + 4 * k];
                     const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float u = z1[k][e];                     // gelu_tanh(u) = u * sigmoid(2 sqrt(2/pi) (u + 0.044715 u^3))
-                        const float hv = u * __builtin_amdgcn_rcpf(1.f + __expf(-1.5957691216057308f * (u + 0.044715f * u * u * u)));
+                    for (int e = 0; e < 2; ++e) {
+                        const f32x2 u = z1[k][e];                     // gelu_tanh(u) = u * sigmoid(2 sqrt(2/pi) (u + 0.044715 u^3))
+                        const f32x2 a = -1.5957691216057308f * (u + 0.044715f * u * u * u);
+                        const f32x2 hv = u * f32x2{__builtin_amdgcn_rcpf(1.f + __expf(a[0])), __builtin_amdgcn_rcpf(1.f + __expf(a[1]))};
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) zz[m][e] = fmaf(ww[m], hv, zz[m][e]);
+                        for (int m = 0; m < 4; ++m) zz[m][e] = __builtin_elementwise_fma(f32x2{ww[m], ww[m]}, hv, zz[m][e]);
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int g = 4 * q4 + e;
-                    const float g0 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[0][e])), g1 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[1][e]));
-                    const float g2 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[2][e]));
+                    const float g0 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[0][e >> 1][e & 1])), g1 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[1][e >> 1][e & 1]));
+                    const float g2 = __builtin_amdgcn_rcpf(1.f + __expf(-zz[2][e >> 1][e & 1]));
                     S0[g] = fmaf(g0, O[g], S0[g]);
                     S0[g] = fmaf(g1, L[g], S0[g]);
                     S0[g] = fmaf(-nb * g2, O[g], S0[g]);
-                    G3d[g] = __builtin_amdgcn_rcpf(1.f + __expf(-zz[3][e]));
+                    G3d[g] = __builtin_amdgcn_rcpf(1.f + __expf(-zz[3][e >> 1][e & 1]));
                 }
             }
         } else {

@@ -784,6 +784,9 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
         unsigned short *Qsm = R;                                    // q rows [token][d]: A operand of the S_v^T tiles
         float *wacc = (float *)(R + NP * LDK);                      // [NT][WACC] weight-gradient sums of this (b,h), per wave
         constexpr int WACC = 16 * 16 + 16 * 4 + 4;                  // [c][k]: dW1[k][c] for c < C <= 14, row 15 = db1[k] | dW2^T [k][m] | db2[m]
+        constexpr int RS = 52, STG = 32 * RS + 16;                  // staging row (floats): dz1 16 | f .. 1 .. 16 | h 16 | dz2 4; 16 floats of over-read pad
+        static_assert(NP * LDK * 2 + NT * (WACC + STG) * 4 <= Cfg::R_BYTES, "dense launch A: q rows + tables + staging rows live in R");
+        float *stg = wacc + NT * WACC + w * STG;                    // this wave's 32 staging rows
         {
             const IOT *qp = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
             constexpr int CH = DK / 8;
@@ -798,7 +801,7 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             for (int c = tid; c < 16; c += NTH) Wsm[18 * 16 + c] = dw.b1[c];
             for (int c = tid; c < 64; c += NTH) Wsm[320 + (c % 16) * 4 + c / 16] = dw.W2[c];
             if (tid < 4) Wsm[384 + tid] = dw.b2[tid];
-            for (int c = tid; c < NT * WACC; c += NTH) wacc[c] = 0.f;
+            for (int c = tid; c < NT * (WACC + STG); c += NTH) wacc[c] = 0.f;
         }
         __syncthreads();
         float *wme = wacc + w * WACC;
@@ -811,47 +814,14 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
             }
             return acc;
         };
-        // sum over the 64 lanes of sixteen per-lane values: after four halving exchanges lane l holds the sum (over its 16-lane row) of
-        // value idx(l) = 8 b0 + 4 b1 + 2 b2 + b3 (b_i = bit i of l), two more exchanges add the four rows.  The exchanges inside a row
-        // are DPP moves (quad_perm for xor 1 / 2, a row_shl / row_shr pair for xor 4 / 8: VALU rate, no LDS crossbar)
-        auto xchg = [&](float x, int step) -> float {                   // value of lane (l ^ step), step in {1, 2, 4, 8}
-            const int xi = __builtin_bit_cast(int, x);
-            int y;
-            if (step == 1) y = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xf, 0xf, true);           // quad_perm [1,0,3,2]
-            else if (step == 2) y = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
-            else if (step == 4) {
-                const int up = __builtin_amdgcn_update_dpp(0, xi, 0x104, 0xf, 0xf, true);          // row_shl:4 (from lane + 4)
-                const int dn = __builtin_amdgcn_update_dpp(0, xi, 0x114, 0xf, 0xf, true);          // row_shr:4 (from lane - 4)
-                y = (lane & 4) ? dn : up;
-            } else {
-                const int up = __builtin_amdgcn_update_dpp(0, xi, 0x108, 0xf, 0xf, true);
-                const int dn = __builtin_amdgcn_update_dpp(0, xi, 0x118, 0xf, 0xf, true);
-                y = (lane & 8) ? dn : up;
-            }
-            return __builtin_bit_cast(float, y);
-        };
-        auto reduce16 = [&](const float (&v)[16]) -> float {
-            float a8[8], a4[4], a2[2];
-            const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a8[i] = (b0 ? v[8 + i] : v[i]) + xchg(b0 ? v[i] : v[8 + i], 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a4[i] = (b1 ? a8[4 + i] : a8[i]) + xchg(b1 ? a8[i] : a8[4 + i], 2);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a2[i] = (b2 ? a4[2 + i] : a4[i]) + xchg(b2 ? a4[i] : a4[2 + i], 4);
-            float s = (b3 ? a2[1] : a2[0]) + xchg(b3 ? a2[0] : a2[1], 8);
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            return s;
-        };
-        const int ridx = ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);   // slot this lane ends up with
-        const IOT *krow = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh + (int64_t)qi * a.k.sn;
+        typedef __attribute__((ext_vector_type(2))) float f32x2;   // the two edges of a pass: v_pk_fma_f32 / v_pk_mul_f32 do both per issue
+        auto bc = [](float x) -> f32x2 { return f32x2{x, x}; };
+        f32x4 aw1 = {0.f, 0.f, 0.f, 0.f}, aw2 = aw1;                // dz1 (x) [f, 1] and h (x) dz2 sums of this wave (16x16 accumulator tiles)
+        float db2a[4] = {0.f, 0.f, 0.f, 0.f};                       // per-lane db2 partials
 #pragma nounroll
         for (int t = 0; t < NT; ++t) {
-            // the q / k fragments of this lane's token and the tile's dP stay resident across the register groups
-            bf16x8 qraw_t[KS], kraw_t[KS];
-            make_frag(qraw_t, qrow, nullptr);
-            make_frag(kraw_t, krow, nullptr);
+            // the tile's dP stays resident across the register groups; the q / k fragments of this lane's token are re-read from the
+            // LDS images per group (32 fewer registers live through the MLP part)
             f32x16 dPt;
             {
                 bf16x8 dyf_t[KS];
@@ -868,204 +838,179 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 // packed tiles hold elements 2d, 2d + 1 in dword d of the (lo | hi) pair of 16-byte vectors
                 auto getw = [&](const u32x4 *p, int g) -> unsigned int { return ((const unsigned int *)&p[(2 * t + (g >> 3)) * 64])[(g >> 1) & 3]; };
                 auto putw = [&](u32x4 *p, int g, float x0, float x1) { ((unsigned int *)&p[(2 * t + (g >> 3)) * 64])[(g >> 1) & 3] = pack_bf16(x0, x1); };
-                float dSq[E], Lq[E], Crq[E], Clq[E];
+                f32x2 dSq, Lq, Crq, Clq;
                 {
                     const float *lp = (const float *)((const f32x4 *)(svb + SL.oL + (size_t)w * 2 * Cfg::SLOT) + lane);     // [4 t + q][lane] x 16 B
+                    const int g = g0;
+                    const unsigned int sm = getw(slot(S_SM), g), cf = getw(slot(S_CF), g), cb = getw(slot(S_CB), g);
+                    const float2 l2 = *(const float2 *)&lp[(size_t)(4 * t + (g >> 2)) * 64 * 4 + (g & 3)];
+                    const float smx[2] = {h2_lo(sm), h2_hi(sm)}, lv[2] = {l2.x, l2.y};
 #pragma unroll
-                    for (int e2 = 0; e2 < E; e2 += 2) {
-                        const int g = g0 + e2;
-                        const unsigned int sm = getw(slot(S_SM), g), cf = getw(slot(S_CF), g), cb = getw(slot(S_CB), g);
-                        const float2 l2 = *(const float2 *)&lp[(size_t)(4 * t + (g >> 2)) * 64 * 4 + (g & 3)];
-                        const float smx[2] = {h2_lo(sm), h2_hi(sm)}, lv[2] = {l2.x, l2.y};
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 32 * t + tile_row(g + e, h);
+                        float dp = dPt[g + e];
+                        if (drop.thresh) dp = fa_drop_keep(drop, rowh, j) ? dp * drop.inv_keep : 0.f;
+                        const float P = __expf(smx[e] - mxrow) * invl;
+                        dSq[e] = keep_if(j < N, P * (dp - delta));
+                        Lq[e] = lv[e] * 0.6931471805599453f;
+                        Crq[e] = __logf(bf2f((unsigned short)(cf >> (16 * e))) + EPSC);
+                        Clq[e] = __logf(bf2f((unsigned short)(cb >> (16 * e))) + EPSC);
+                    }
+                }
+                // ---- all views' scores of the group's two edges from ONE matrix-core chain per operand order: the 32 A rows are
+                //      (key, view) pairs -- row m feeds accumulator register (m & 3) + 4 (m >> 3) of lane half (m >> 2) & 1, so register v
+                //      (8 + v) of a lane is S_v of its first (second) edge -- and each A lane scales its key's row by its view's sqk on the
+                //      way in (8 products per k-step, instead of re-scaling this lane's token per view and running V chains)
+                f32x16 aS = zero16(), aT = zero16();
+                {
+                    const int m = lane & 31, hp = (m >> 2) & 1, gq = (m & 3) + 4 * (m >> 3), va = min(gq & 7, V - 1);
+                    const int key = 32 * t + tile_row(g0 + (gq >> 3), hp);
+                    const float *sca = sqk + va * DK + 8 * h;
+                    const unsigned short *kr = Ksm + key * LDK + 8 * h, *qr = Qsm + key * LDK + 8 * h;
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int j = 32 * t + tile_row(g + e, h);
-                            float dp = dPt[g + e];
-                            if (drop.thresh) dp = fa_drop_keep(drop, rowh, j) ? dp * drop.inv_keep : 0.f;
-                            const float P = __expf(smx[e] - mxrow) * invl;
-                            dSq[e2 + e] = keep_if(j < N, P * (dp - delta));
-                            Lq[e2 + e] = lv[e] * 0.6931471805599453f;
-                            Crq[e2 + e] = __logf(bf2f((unsigned short)(cf >> (16 * e))) + EPSC);
-                            Clq[e2 + e] = __logf(bf2f((unsigned short)(cb >> (16 * e))) + EPSC);
+                    for (int s = 0; s < KS; ++s) {
+                        const float4 s0 = *(const float4 *)&sca[16 * s], s1 = *(const float4 *)&sca[16 * s + 4];
+                        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                        const bf16x8 rk = *(const bf16x8 *)&kr[16 * s], rq = *(const bf16x8 *)&qr[16 * s];
+                        bf16x8 ak, aq;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            ak[j] = (short)f2bf(bf2f((unsigned short)rk[j]) * sc[j]);
+                            aq[j] = (short)f2bf(bf2f((unsigned short)rq[j]) * sc[j]);
                         }
+                        const bf16x8 qmine = *(const bf16x8 *)&Qsm[(32 * w + r) * LDK + 16 * s + 8 * h];
+                        const bf16x8 kmine = *(const bf16x8 *)&Ksm[(32 * w + r) * LDK + 16 * s + 8 * h];
+                        aS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qmine, aS, 0, 0, 0);      // S_v(i, j) = (k_j * sqk_v) . q_i
+                        aT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kmine, aT, 0, 0, 0);      // S_v(j, i) = (q_j * sqk_v) . k_i
                     }
                 }
-                // ---- features and first layer: z1[e][k] = b1[k] + sum_c W1[k][c] f_c[e]
-                f32x16 z1[E];                                       // z1[e][k]: pre-activation (later dz1) of hidden unit k for edge e; k may be a runtime index
-                f32x16 F[E];                                        // F[e][c]: feature channel c of edge e (C <= 14), kept for the second pass
-#pragma unroll
-                for (int e = 0; e < E; ++e) F[e] = zero16();
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
-                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                        for (int e = 0; e < E; ++e) z1[e][4 * k4 + kk] = bb[kk];
-                }
-                auto accum = [&](int c, const float (&f)[E]) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) F[e][c] = f[e];
-#pragma unroll
-                    for (int k4 = 0; k4 < 4; ++k4) {
-                        const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
-                        const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                            for (int e = 0; e < E; ++e) z1[e][4 * k4 + kk] = fmaf(ww[kk], f[e], z1[e][4 * k4 + kk]);
-                    }
-                };
-                float Oq[E], S0q[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) { Oq[e] = 0.f; S0q[e] = 0.f; }
-                {
-                    bf16x8 qe[KS];
-                    for (int v = 0; v < V; ++v) {
-                        scale_frag(qe, qraw_t, sqk + v * DK);
-                        const f32x16 Sv = s_tile(qe, t);
-                        float fs[E];
-#pragma unroll
-                        for (int e = 0; e < E; ++e) fs[e] = Sv[g0 + e];
-                        accum(v, fs);
-#pragma unroll
-                        for (int e = 0; e < E; ++e) { if (v == 0) S0q[e] = fs[e]; else Oq[e] += fs[e]; }
-                        scale_frag(qe, kraw_t, sqk + v * DK);
-                        const f32x16 Tv = st_tile(qe, t);
-                        float ft[E];
-#pragma unroll
-                        for (int e = 0; e < E; ++e) ft[e] = Tv[g0 + e];
-                        accum(V + v, ft);
-                    }
-                }
-                accum(2 * V, Crq);
-                accum(2 * V + 1, Clq);
-                // ---- second layer and gates
-                float zz[4][E];
-                {
-                    const float4 bv = *(const float4 *)&Wsm[384];
-                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int e = 0; e < E; ++e) zz[m][e] = bb[m];
-                }
+                // ---- the MLP, one edge at a time (rolled: the per-edge state -- 16 pre-activations, 16 hidden values, the feature vector --
+                //      stays inside the register budget; two edges at once spilled ~90 scratch accesses per group into the hot loop)
+                f32x16 O0 = zero16();                               // first edge's channel outputs, kept until the second edge's are known (one packed store)
 #pragma nounroll
-                for (int k = 0; k < 16; ++k) {
-                    const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
-                    const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const float u = z1[e][k];
-                        const float hv = u * __builtin_amdgcn_rcpf(1.f + __expf(-1.5957691216057308f * (u + 0.044715f * u * u * u)));
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) zz[m][e] = fmaf(ww[m], hv, zz[m][e]);
-                    }
-                }
-                float G[4][E], dzz[4][E];
-#pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const float term[4] = {Oq[e], Lq[e], -nb * Oq[e], Crq[e]};    // d Smix / d G_g: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        G[m][e] = __builtin_amdgcn_rcpf(1.f + __expf(-zz[m][e]));
-                        dzz[m][e] = dSq[e] * term[m] * G[m][e] * (1.f - G[m][e]);
-                    }
-                }
-                // ---- db2, then per hidden unit: h, gelu', dh, dz1 (in place of z1), dW2^T row
-                {
-                    float pb[4];
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) { float sacc = 0.f;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) sacc += dzz[m][e];
-                        pb[m] = wave_sum(sacc); }
-                    if (lane < 4) wme[16 * 16 + 16 * 4 + lane] += lane == 0 ? pb[0] : lane == 1 ? pb[1] : lane == 2 ? pb[2] : pb[3];
-                }
-                f32x16 hq[E];                                       // hq[e][k] = gelu(z1[e][k]): operand of the dW2 rows below
-#pragma nounroll
-                for (int k = 0; k < 16; ++k) {
-                    const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
-                    const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const float u = z1[e][k];
-                        const float arg = 1.5957691216057308f * (u + 0.044715f * u * u * u);
-                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-arg));
-                        const float hv = u * sg;
-                        const float gp = sg + hv * (1.f - sg) * 1.5957691216057308f * (1.f + 0.134145f * u * u);     // d gelu_tanh / du
-                        float dh = 0.f;
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) dh = fmaf(ww[m], dzz[m][e], dh);
-                        z1[e][k] = dh * gp;                          // dz1
-                        hq[e][k] = hv;
-                    }
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {                         // dW2[m][:] = sum_e dz2[m][e] h[:][e]: one 16-wide butterfly per gate
-                    float row[16];
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) { float sacc = 0.f;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) sacc = fmaf(dzz[m][e], hq[e][k], sacc);
-                        row[k] = sacc; }
-                    const float rs = reduce16(row);
-                    if ((lane >> 4) == 0) wme[16 * 16 + 4 * ridx + m] += rs;      // table [k][m]
-                }
-                // ---- second pass over the channels: dW1[:, c] = sum_e dz1[:, e] f_c[e] reduced over the wave (16 hidden units = one
-                //      butterfly), df_c = sum_k W1[k][c] dz1[k] -> hand-off slabs
-                float g1q[E], gAq[E], lseq[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) { g1q[e] = G[1][e]; gAq[e] = fmaf(-nb, G[2][e], G[0][e]); lseq[e] = Lq[e] + S0q[e]; }
-                {
-                    float row[16];                                   // db1[k] = sum_e dz1[e][k]
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) { float sacc = 0.f;
-#pragma unroll
-                        for (int e = 0; e < E; ++e) sacc += z1[e][k];
-                        row[k] = sacc; }
-                    const float rs = reduce16(row);
-                    if ((lane >> 4) == 0) wme[16 * 15 + ridx] += rs;      // slot row 15 of the [c][k] table (C <= 14)
-                }
-                for (int c = 0; c < C; ++c) {
-                    float f[E];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) f[e] = F[e][c];
-                    float row[16], df[E];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) df[e] = 0.f;
+                    const float dSe = e ? dSq[1] : dSq[0], Le = e ? Lq[1] : Lq[0], Cre = e ? Crq[1] : Crq[0], Cle = e ? Clq[1] : Clq[0];
+                    float z1[16];                                   // pre-activation, then gelu', then dz1 of hidden unit k
+                    f32x16 F = zero16();                            // F[c]: feature channel c (C <= 14), slot C = 1 (the bias column); c may be a runtime index
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
-                        const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
-                        const float ww[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+                        const float4 bv = *(const float4 *)&Wsm[18 * 16 + 4 * k4];
+                        z1[4 * k4] = bv.x; z1[4 * k4 + 1] = bv.y; z1[4 * k4 + 2] = bv.z; z1[4 * k4 + 3] = bv.w;
+                    }
+                    auto accum = [&](int c, float f) {
+                        F[c] = f;
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const int k = 4 * k4 + kk;
-                            float sacc = 0.f;
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            const float4 wv4 = *(const float4 *)&Wsm[c * 16 + 4 * k4];
+                            z1[4 * k4] = fmaf(wv4.x, f, z1[4 * k4]); z1[4 * k4 + 1] = fmaf(wv4.y, f, z1[4 * k4 + 1]);
+                            z1[4 * k4 + 2] = fmaf(wv4.z, f, z1[4 * k4 + 2]); z1[4 * k4 + 3] = fmaf(wv4.w, f, z1[4 * k4 + 3]);
+                        }
+                    };
+                    float Oe = 0.f, S0e = 0.f;
 #pragma unroll
-                            for (int e = 0; e < E; ++e) { sacc = fmaf(z1[e][k], f[e], sacc); df[e] = fmaf(ww[kk], z1[e][k], df[e]); }
-                            row[k] = sacc;
+                    for (int v = 0; v < 8; ++v) {
+                        if (v < V) {
+                            const float fs = e ? aS[8 + v] : aS[v];
+                            accum(v, fs);
+                            if (v == 0) S0e = fs; else Oe += fs;
+                            accum(V + v, e ? aT[8 + v] : aT[v]);
                         }
                     }
-                    const float rs = reduce16(row);
-                    if ((lane >> 4) == 0) wme[16 * c + ridx] += rs;       // [c][k]: dW1[k][c]
-                    // one store site for every channel kind (the slab id and the value are selected arithmetically): S_v channels -> DIR_v
-                    // (direct score gradient dSmix * coef_v + df), S_v^T channels -> their own slabs (gradient of S_v(j, i), added transposed
-                    // by launch C), Cr -> C3 (joins the chain-gate term G_chain dSmix), Cl -> the slab that seeds the <- D-chain (launch B)
-                    const int sid = c < V ? X_DIR + c : (c < 2 * V ? X_DT(V) + (c - V) : (c == 2 * V ? (int)X_C3 : X_CL(V)));
-                    float o[E];
-#pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        const float pi = __expf(fminf(f[e] - lseq[e], 0.f));          // only meaningful for the S_v channels (pi <= 1 there)
-                        const float coef = c == 0 ? (1.f - g1q[e]) + g1q[e] * pi : fmaf(g1q[e], pi, gAq[e]);
-                        const float direct = c < V ? dSq[e] * coef : (c == 2 * V ? dSq[e] * G[3][e] : 0.f);
-                        o[e] = direct + df[e];
+                    accum(2 * V, Cre);
+                    accum(2 * V + 1, Cle);
+                    F[C] = 1.f;
+                    // gelu, its derivative (kept in place of z1: no transcendental in the second sweep), second layer and gates
+                    float zz[4], hq[16];
+                    {
+                        const float4 bv = *(const float4 *)&Wsm[384];
+                        zz[0] = bv.x; zz[1] = bv.y; zz[2] = bv.z; zz[3] = bv.w;
                     }
-                    u32x4 *ps = slot(sid);
 #pragma unroll
-                    for (int e2 = 0; e2 < E; e2 += 2) putw(ps, g0 + e2, o[e2], o[e2 + 1]);
+                    for (int k = 0; k < 16; ++k) {
+                        const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
+                        const float u = z1[k], u2 = u * u;
+                        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-1.5957691216057308f * (u + 0.044715f * u * u2)));
+                        const float hv = u * sg;
+                        z1[k] = sg + hv * (1.f - sg) * (1.5957691216057308f + 0.21406444881780076f * u2);     // d gelu_tanh / du
+                        hq[k] = hv;
+                        zz[0] = fmaf(wv4.x, hv, zz[0]); zz[1] = fmaf(wv4.y, hv, zz[1]); zz[2] = fmaf(wv4.z, hv, zz[2]); zz[3] = fmaf(wv4.w, hv, zz[3]);
+                    }
+                    float G[4], dzz[4];
+                    {
+                        const float term[4] = {Oe, Le, -nb * Oe, Cre};  // d Smix / d G_g: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
+#pragma unroll
+                        for (int mg = 0; mg < 4; ++mg) {
+                            G[mg] = __builtin_amdgcn_rcpf(1.f + __expf(-zz[mg]));
+                            dzz[mg] = dSe * term[mg] * G[mg] * (1.f - G[mg]);
+                            db2a[mg] += dzz[mg];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {                    // dz1 = (W2^T dz2) * gelu'
+                        const float4 wv4 = *(const float4 *)&Wsm[320 + 4 * k];
+                        z1[k] *= fmaf(wv4.w, dzz[3], fmaf(wv4.z, dzz[2], fmaf(wv4.y, dzz[1], wv4.x * dzz[0])));
+                    }
+                    // weight-gradient sums on the f32 matrix core: per lane half, 32 rows parked, 8 k-steps of 4 edges
+#pragma unroll
+                    for (int hs = 0; hs < 2; ++hs) {
+                        if (h == hs) {
+                            f32x4 *row = (f32x4 *)(stg + r * RS);
+#pragma unroll
+                            for (int k4 = 0; k4 < 4; ++k4) {
+                                row[k4] = f32x4{z1[4 * k4], z1[4 * k4 + 1], z1[4 * k4 + 2], z1[4 * k4 + 3]};
+                                row[4 + k4] = f32x4{F[4 * k4], F[4 * k4 + 1], F[4 * k4 + 2], F[4 * k4 + 3]};
+                                row[8 + k4] = f32x4{hq[4 * k4], hq[4 * k4 + 1], hq[4 * k4 + 2], hq[4 * k4 + 3]};
+                            }
+                            row[12] = f32x4{dzz[0], dzz[1], dzz[2], dzz[3]};
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const float *rd = stg + (lane >> 4) * RS + (lane & 15);
+#pragma unroll
+                        for (int s4 = 0; s4 < 8; ++s4) {
+                            const float *q4 = rd + 4 * s4 * RS;
+                            aw1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[0], q4[16], aw1, 0, 0, 0);
+                            aw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(q4[32], q4[48], aw2, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    // channels: df_c = sum_k W1[k][c] dz1[k] -> hand-off slabs (rolled: unrolled over the channels it spills into the hot loop)
+                    const float g1e = G[1], gAe = fmaf(-nb, G[2], G[0]), lsee = Le + S0e;
+                    for (int c = 0; c < C; ++c) {
+                        const float f = F[c];
+                        const float4 *wr = (const float4 *)&Wsm[c * 16];
+                        const float4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+                        float d0 = w0.x * z1[0], d1 = w1.x * z1[4], d2 = w2.x * z1[8], d3 = w3.x * z1[12];       // four independent chains
+                        d0 = fmaf(w0.y, z1[1], d0); d1 = fmaf(w1.y, z1[5], d1); d2 = fmaf(w2.y, z1[9], d2); d3 = fmaf(w3.y, z1[13], d3);
+                        d0 = fmaf(w0.z, z1[2], d0); d1 = fmaf(w1.z, z1[6], d1); d2 = fmaf(w2.z, z1[10], d2); d3 = fmaf(w3.z, z1[14], d3);
+                        d0 = fmaf(w0.w, z1[3], d0); d1 = fmaf(w1.w, z1[7], d1); d2 = fmaf(w2.w, z1[11], d2); d3 = fmaf(w3.w, z1[15], d3);
+                        // one store site for every channel kind (the slab id and the value are selected arithmetically): S_v channels -> DIR_v
+                        // (direct score gradient dSmix * coef_v + df), S_v^T channels -> their own slabs (gradient of S_v(j, i), added transposed
+                        // by launch C), Cr -> C3 (joins the chain-gate term G_chain dSmix), Cl -> the slab that seeds the <- D-chain (launch B)
+                        const int sid = c < V ? X_DIR + c : (c < 2 * V ? X_DT(V) + (c - V) : (c == 2 * V ? (int)X_C3 : X_CL(V)));
+                        const float pi = __expf(fminf(f - lsee, 0.f));              // only meaningful for the S_v channels (pi <= 1 there)
+                        const float coef = c == 0 ? (1.f - g1e) + g1e * pi : fmaf(g1e, pi, gAe);
+                        const float direct = c < V ? dSe * coef : (c == 2 * V ? dSe * G[3] : 0.f);
+                        const float o = direct + ((d0 + d1) + (d2 + d3));
+                        if (e == 0) O0[c] = o;
+                        else putw(slot(sid), g0, O0[c], o);
+                    }
                 }
+            }
+        }
+        // the wave's accumulator tiles -> its table: D[row = 4 (lane >> 4) + i][col = lane & 15]
+        {
+            const int col = lane & 15, row0 = 4 * (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (col <= C) wme[16 * (col < C ? col : 15) + row0 + i] = aw1[i];      // [c][k]; column C = the bias column -> row 15
+                if (col < 4) wme[16 * 16 + 4 * (row0 + i) + col] = aw2[i];             // dW2^T [k][m]
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float sb = wave_sum(db2a[m]);
+                if (lane == 0) wme[16 * 16 + 16 * 4 + m] = sb;
             }
         }
         __syncthreads();
