@@ -618,30 +618,57 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
                         for (int e = 0; e < 2; ++e) z1[4 * k4 + kk][e] = f32x2{bb[kk], bb[kk]};
                 }
-                auto accum = [&](int c, const f32x16 &F) {             // z1 += W1[:, c] (x) f, f = registers 4 q4 .. 4 q4 + 3 of F
-                    const f32x2 f[2] = {f32x2{F[4 * q4], F[4 * q4 + 1]}, f32x2{F[4 * q4 + 2], F[4 * q4 + 3]}};
+                auto accum = [&](int c, int e, f32x2 f) {              // z1[:, pair e] += W1[:, c] (x) f, f = two of the quarter's four edges
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
                         const float4 wv = *(const float4 *)&Wsm[c * 16 + 4 * k4];
-                        const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                            for (int e = 0; e < 2; ++e)
-                                z1[4 * k4 + kk][e] = __builtin_elementwise_fma(f32x2{ww[kk], ww[kk]}, f[e], z1[4 * k4 + kk][e]);
+                        z1[4 * k4][e] = __builtin_elementwise_fma(f32x2{wv.x, wv.x}, f, z1[4 * k4][e]);
+                        z1[4 * k4 + 1][e] = __builtin_elementwise_fma(f32x2{wv.y, wv.y}, f, z1[4 * k4 + 1][e]);
+                        z1[4 * k4 + 2][e] = __builtin_elementwise_fma(f32x2{wv.z, wv.z}, f, z1[4 * k4 + 2][e]);
+                        z1[4 * k4 + 3][e] = __builtin_elementwise_fma(f32x2{wv.w, wv.w}, f, z1[4 * k4 + 3][e]);
                     }
                 };
                 {
-                    bf16x8 qe[KS];
-                    for (int v = 0; v < V; ++v) {
-                        scale_qe(qe, qraw, v);
-                        accum(v, s_tile(qe, t));
-                        scale_qe(qe, kraw, v);
-                        accum(V + v, st_tile(qe, t));
+                    // All views' scores of two edges per lane from ONE matrix-core chain per operand order: the 32 A rows are (key, view)
+                    // pairs -- row m feeds accumulator register (m & 3) + 4 (m >> 3) of lane half (m >> 2) & 1, so register v (8 + v) of
+                    // a lane is S_v of its first (second) edge -- and each A lane scales its key's row by its view's sqk on the way in.
+                    // Two such pairs per quarter: 16 MFMAs and 4 x 8 products per k-step instead of 2V chains and 2V re-scaled fragments.
+                    const int m = lane & 31, hp = (m >> 2) & 1, gq = (m & 3) + 4 * (m >> 3), va = min(gq & 7, V - 1);
+                    const float *sca = sqk + va * DK + 8 * h;
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const int key = 32 * t + tile_row(4 * q4 + 2 * pr + (gq >> 3), hp);
+                        const unsigned short *kr = Ksm + key * LDK + 8 * h, *qr = bT + key * LDK + 8 * h;
+                        f32x16 xs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, xt = xs;
+#pragma unroll
+                        for (int s = 0; s < KS; ++s) {
+                            const float4 s0 = *(const float4 *)&sca[16 * s], s1 = *(const float4 *)&sca[16 * s + 4];
+                            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+                            const bf16x8 rk = *(const bf16x8 *)&kr[16 * s], rq = *(const bf16x8 *)&qr[16 * s];
+                            bf16x8 ak, aq;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                ak[j] = (short)f2bf(bf2f((unsigned short)rk[j]) * sc[j]);
+                                aq[j] = (short)f2bf(bf2f((unsigned short)rq[j]) * sc[j]);
+                            }
+                            xs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qraw[s], xs, 0, 0, 0);      // S_v(i, j) = (k_j * sqk_v) . q_i
+                            xt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kraw[s], xt, 0, 0, 0);      // S_v(j, i) = (q_j * sqk_v) . k_i
+                        }
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            if (v < V) {
+                                accum(v, pr, f32x2{xs[v], xs[8 + v]});
+                                accum(V + v, pr, f32x2{xt[v], xt[8 + v]});
+                            }
+                        }
+                        asm volatile("" ::: "memory");              // the second pair's chain after the first pair's accumulation (live ranges)
                     }
                 }
-                accum(2 * V, Crv);
-                accum(2 * V + 1, Clv);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    accum(2 * V, e, f32x2{Crv[4 * q4 + 2 * e], Crv[4 * q4 + 2 * e + 1]});
+                    accum(2 * V + 1, e, f32x2{Clv[4 * q4 + 2 * e], Clv[4 * q4 + 2 * e + 1]});
+                }
                 f32x2 zz[4][2];
                 {
                     const float4 bv = *(const float4 *)&Wsm[384];
