@@ -775,11 +775,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
     }
     } else {
     // ================= dense gate head (HEAD == 1; reference :250-272 minus the 3x3, :312-318) =================
-    // Per register quarter of every tile (four edges per lane): features f = [S_v, S_v^T, Cr, Cl] recomputed on the matrix core, MLP
-    // forward (gates), mix backward dG_g = dSmix * term_g, MLP backward -> dz2, dz1, df.  df joins the direct score gradients (S_v
-    // channels: DIR_v; S_v^T channels: their own slabs, added transposed by launch C), C3 (Cr) and a new slab (Cl, seeds the <- chain in
-    // launch B).  Weight gradients: per hidden unit the 16 per-lane partial sums [dW1[k][:], db1[k]] are reduced over the wave with a
-    // halving butterfly (17 shuffles per row instead of 96) and accumulated per wave in LDS.
+    // Per pair of tile registers (two edges per lane): features f = [S_v, S_v^T, Cr, Cl] recomputed on the matrix core (one chain per
+    // operand order for all views), then per edge the MLP forward (gates), the mix backward dG_g = dSmix * term_g and the MLP backward
+    // -> dz2, dz1, df.  df joins the direct score gradients (S_v channels: DIR_v; S_v^T channels: their own slabs, added transposed by
+    // launch C), C3 (Cr) and a new slab (Cl, seeds the <- chain in launch B).  Weight gradients are sums over edges = sums over lanes,
+    // which no MFMA contracts: each half-wave parks its edges' rows [dz1 | f, 1 | h | dz2] (fp32) in a wave-private LDS buffer and
+    // v_mfma_f32_16x16x4_f32 (exact fp32) sums dz1 (x) [f, 1] and h (x) dz2 over them, four edges per issue; the two accumulator
+    // tiles live in registers for the whole (b,h).
     {
         unsigned short *Qsm = R;                                    // q rows [token][d]: A operand of the S_v^T tiles
         float *wacc = (float *)(R + NP * LDK);                      // [NT][WACC] weight-gradient sums of this (b,h), per wave
@@ -828,9 +830,8 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
                 make_frag(dyf_t, dyrow, nullptr);
                 dPt = g_tile(V0s, dyf_t, t);                        // dP = dy v0^T for the whole tile; quarters index into it
             }
-            // E edges per lane and pass: registers E qq .. E qq + E - 1 of the tile.  E = 2 keeps the body (32 pre-activations, the held
-            // fragments, the butterfly rows) inside the register budget; with E = 4 it spilled 290 registers and the launch was bound
-            // by its own scratch traffic.  The price is twice the score-tile recompute, which the idle matrix pipe absorbs.
+            // E edges per lane and pass: registers E qq .. E qq + E - 1 of the tile.  E = 2 is what one (key, view)-row chain covers for
+            // V <= 8 (16 accumulator registers per lane half); the MLP then runs per edge.
             constexpr int E = 2, NQ = 16 / E;
 #pragma nounroll
             for (int qq = 0; qq < NQ; ++qq) {
