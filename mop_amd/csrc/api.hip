@@ -89,7 +89,7 @@ int mopk_edgewise_fused_supported(const MopkEdgewiseArgs *a) { return a ? ew_fus
 
 const char *mopk_edgewise_dominant_kernel(const MopkEdgewiseArgs *a, int backward) {
     const bool fused = a && a->path != MOPK_PATH_GENERIC && ew_fused_fwd_supported(a);
-    if (!fused) return "bgemm_kernel";
+    if (!fused) return a && a->precision == MOPK_PREC_BF16 ? "bgemm_mfma_kernel" : "bgemm_kernel";
     return backward ? "ew_fused_bwd_kernel" : "ew_fused_fwd_kernel";
 }
 

@@ -23,9 +23,115 @@ struct GemmDesc {
     float beta;
 };
 
-constexpr int GB_M = 64, GB_N = 64, GB_K = 32;
+constexpr int GB_M = 64, GB_N = 64, GB_K = 32, GB_LD = GB_K + 8;
 
-template <bool MFMA, bool A_KC, bool B_NC>
+// One operand tile of the bf16 path: 64 rows x 32 k of X(r, k) = X[r * rs + k * cs] -> registers (8 values per thread) -> LDS image
+// [row][k] bf16 (row stride 40: 16-byte fragment reads without bank conflicts).  KC: k is the contiguous index (two 16-byte loads per
+// thread, one 16-byte LDS store); otherwise rows are (four rows x two k per thread: two 16-byte loads, four packed 4-byte stores).
+// `vec` = the host checked stride-1 / alignment; chunks that cross the matrix edge, and unaligned operands, take the scalar loads.
+template <bool KC>
+struct BgStage {
+    float v[8];
+    __device__ __forceinline__ void load(const float *X, int64_t rs, int64_t cs, int r0, int k0, int R, int K, bool vec) {
+        const int t = threadIdx.x;
+        if (KC) {
+            const int r = r0 + (t >> 2), k = k0 + (t & 3) * 8;
+            const float *p = X + (int64_t)r * rs + (int64_t)k * cs;
+            if (vec && r < R && k + 7 < K) {
+                const float4 a = *(const float4 *)p, b = *(const float4 *)(p + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (r < R && k + j < K) ? p[(int64_t)j * cs] : 0.f;
+            }
+        } else {
+            const int r = r0 + (t & 15) * 4, k = k0 + (t >> 4) * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float *p = X + (int64_t)r * rs + (int64_t)(k + j) * cs;
+                if (vec && r + 3 < R && k + j < K) {
+                    const float4 a = *(const float4 *)p;
+                    v[4 * j] = a.x; v[4 * j + 1] = a.y; v[4 * j + 2] = a.z; v[4 * j + 3] = a.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[4 * j + i] = (r + i < R && k + j < K) ? p[(int64_t)i * rs] : 0.f;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short *Xh) const {
+        const int t = threadIdx.x;
+        if (KC) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[j]);
+            *(bf16x8 *)&Xh[(t >> 2) * GB_LD + (t & 3) * 8] = o;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *(unsigned int *)&Xh[((t & 15) * 4 + i) * GB_LD + (t >> 4) * 2] = (unsigned int)f2bf(v[i]) | ((unsigned int)f2bf(v[4 + i]) << 16);
+        }
+    }
+};
+
+// bf16 MFMA variant: the next k-tile is fetched into registers while the matrix core works on the current one
+template <bool A_KC, bool B_NC>
+__global__ __launch_bounds__(256) void bgemm_mfma_kernel(GemmDesc d, bool vecA, bool vecB) {
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[GB_M * GB_LD], Bh[GB_N * GB_LD];
+    const int t = threadIdx.x, bz = blockIdx.z, i0 = bz / d.nb1, i1 = bz % d.nb1;
+    const float *A = d.A + i0 * d.a_b0 + i1 * d.a_b1;
+    const float *B = d.B + i0 * d.b_b0 + i1 * d.b_b1;
+    float *C = d.C + i0 * d.c_b0 + i1 * d.c_b1;
+    const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
+    const int lane = t & 63, wv = t >> 6, wm = wv >> 1, wn = wv & 1;
+    f32x4 macc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) macc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    BgStage<A_KC> sa;
+    BgStage<!B_NC> sb;                   // B(k, n): row index n, "k contiguous" when n is not
+    sa.load(A, d.a_rs, d.a_cs, m0, 0, d.M, d.K, vecA);
+    sb.load(B, d.b_cs, d.b_rs, n0, 0, d.N, d.K, vecB);
+    for (int k0 = 0; k0 < d.K; k0 += GB_K) {
+        sa.store(Ah);
+        sb.store(Bh);
+        __syncthreads();
+        if (k0 + GB_K < d.K) {
+            sa.load(A, d.a_rs, d.a_cs, m0, k0 + GB_K, d.M, d.K, vecA);
+            sb.load(B, d.b_cs, d.b_rs, n0, k0 + GB_K, d.N, d.K, vecB);
+        }
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8 *)&Ah[(wm * 32 + i * 16 + (lane & 15)) * GB_LD + 8 * (lane >> 4)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8 *)&Bh[(wn * 32 + j * 16 + (lane & 15)) * GB_LD + 8 * (lane >> 4)];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) macc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], macc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    float alpha = d.alpha;
+    if (d.alpha_dev) alpha *= *d.alpha_dev;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r, n = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (m < d.M && n < d.N) {
+                    float *p = C + (int64_t)m * d.c_rs + n;
+                    float v = alpha * macc[i][j][r];
+                    if (d.beta != 0.f) v += d.beta * *p;
+                    *p = v;
+                }
+            }
+}
+
+// exact fp32 FMA variant
+template <bool A_KC, bool B_NC>
 __global__ __launch_bounds__(256) void bgemm_kernel(GemmDesc d) {
     __shared__ __attribute__((aligned(16))) float smem[2 * GB_K * (GB_M + 4)];
     const int t = threadIdx.x;
@@ -35,29 +141,15 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmDesc d) {
     const float *B = d.B + i0 * d.b_b0 + i1 * d.b_b1;
     float *C = d.C + i0 * d.c_b0 + i1 * d.c_b1;
     const int m0 = blockIdx.y * GB_M, n0 = blockIdx.x * GB_N;
-
-    float *As = smem;                           // fp32: [GB_K][GB_M+4]
-    float *Bs = smem + GB_K * (GB_M + 4);       // fp32: [GB_K][GB_N+4]
-    unsigned short *Ah = (unsigned short *)smem;            // bf16: [GB_M][GB_K+8]
-    unsigned short *Bh = Ah + GB_M * (GB_K + 8);            // bf16: [GB_N][GB_K+8]
-
+    float *As = smem;                           // [GB_K][GB_M+4]
+    float *Bs = smem + GB_K * (GB_M + 4);       // [GB_K][GB_N+4]
     float acc[4][4];
-    f32x4 macc[2][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) macc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int lane = t & 63, wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
     const int tx = t & 15, ty = t >> 4;
-
     for (int k0 = 0; k0 < d.K; k0 += GB_K) {
-        // ---- stage A tile (GB_M x GB_K) and B tile (GB_K x GB_N) ----
 #pragma unroll
         for (int i = 0; i < (GB_M * GB_K) / 256; ++i) {
             int idx = t + 256 * i;
@@ -65,7 +157,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmDesc d) {
             if (A_KC) { k = idx % GB_K; m = idx / GB_K; } else { m = idx % GB_M; k = idx / GB_M; }
             float v = 0.f;
             if (m0 + m < d.M && k0 + k < d.K) v = A[(int64_t)(m0 + m) * d.a_rs + (int64_t)(k0 + k) * d.a_cs];
-            if (MFMA) Ah[m * (GB_K + 8) + k] = f2bf(v); else As[k * (GB_M + 4) + m] = v;
+            As[k * (GB_M + 4) + m] = v;
         }
 #pragma unroll
         for (int i = 0; i < (GB_N * GB_K) / 256; ++i) {
@@ -74,84 +166,57 @@ __global__ __launch_bounds__(256) void bgemm_kernel(GemmDesc d) {
             if (B_NC) { n = idx % GB_N; k = idx / GB_N; } else { k = idx % GB_K; n = idx / GB_K; }
             float v = 0.f;
             if (n0 + n < d.N && k0 + k < d.K) v = B[(int64_t)(k0 + k) * d.b_rs + (int64_t)(n0 + n) * d.b_cs];
-            if (MFMA) Bh[n * (GB_K + 8) + k] = f2bf(v); else Bs[k * (GB_N + 4) + n] = v;
+            Bs[k * (GB_N + 4) + n] = v;
         }
         __syncthreads();
-        if (MFMA) {
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = *(const bf16x8 *)&Ah[(wm * 32 + i * 16 + (lane & 15)) * (GB_K + 8) + 8 * (lane >> 4)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bfr[j] = *(const bf16x8 *)&Bh[(wn * 32 + j * 16 + (lane & 15)) * (GB_K + 8) + 8 * (lane >> 4)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    macc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], macc[i][j], 0, 0, 0);
-        } else {
 #pragma unroll 8
-            for (int k = 0; k < GB_K; ++k) {
-                const float4 a4 = *(const float4 *)&As[k * (GB_M + 4) + ty * 4];
-                const float4 b4 = *(const float4 *)&Bs[k * (GB_N + 4) + tx * 4];
-                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        for (int k = 0; k < GB_K; ++k) {
+            const float4 a4 = *(const float4 *)&As[k * (GB_M + 4) + ty * 4];
+            const float4 b4 = *(const float4 *)&Bs[k * (GB_N + 4) + tx * 4];
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-            }
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
         }
         __syncthreads();
     }
     float alpha = d.alpha;
     if (d.alpha_dev) alpha *= *d.alpha_dev;
-    if (MFMA) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
-                    int n = n0 + wn * 32 + j * 16 + (lane & 15);
-                    if (m < d.M && n < d.N) {
-                        float *p = C + (int64_t)m * d.c_rs + n;
-                        float v = alpha * macc[i][j][r];
-                        if (d.beta != 0.f) v += d.beta * *p;
-                        *p = v;
-                    }
-                }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-                if (m < d.M && n < d.N) {
-                    float *p = C + (int64_t)m * d.c_rs + n;
-                    float v = alpha * acc[i][j];
-                    if (d.beta != 0.f) v += d.beta * *p;
-                    *p = v;
-                }
+        for (int j = 0; j < 4; ++j) {
+            int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < d.M && n < d.N) {
+                float *p = C + (int64_t)m * d.c_rs + n;
+                float v = alpha * acc[i][j];
+                if (d.beta != 0.f) v += d.beta * *p;
+                *p = v;
             }
-    }
+        }
 }
 
 inline int bgemm(const GemmDesc &d, bool mfma, hipStream_t st) {
     if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.nb0 * d.nb1 <= 0) return MOPK_ERR_BAD_SHAPE;
     dim3 grid((d.N + GB_N - 1) / GB_N, (d.M + GB_M - 1) / GB_M, d.nb0 * d.nb1);
     const bool akc = d.a_cs == 1, bnc = d.b_cs == 1;
-#define MOPK_BG(MF, AK, BN_) hipLaunchKernelGGL((bgemm_kernel<MF, AK, BN_>), grid, dim3(256), 0, st, d)
     if (mfma) {
-        if (akc && bnc) MOPK_BG(true, true, true); else if (akc) MOPK_BG(true, true, false);
-        else if (bnc) MOPK_BG(true, false, true); else MOPK_BG(true, false, false);
-    } else {
-        if (akc && bnc) MOPK_BG(false, true, true); else if (akc) MOPK_BG(false, true, false);
-        else if (bnc) MOPK_BG(false, false, true); else MOPK_BG(false, false, false);
-    }
+        // 16-byte loads need the contiguous index to be stride 1 and every other stride / the base to keep 16-byte alignment
+        auto al = [](const float *p, int64_t s0, int64_t s1, int64_t s2) { return ((uintptr_t)p % 16 == 0) && s0 % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0; };
+        const bool vecA = akc ? al(d.A, d.a_rs, d.a_b0, d.a_b1) : (d.a_rs == 1 && al(d.A, d.a_cs, d.a_b0, d.a_b1));
+        const bool vecB = bnc ? al(d.B, d.b_rs, d.b_b0, d.b_b1) : (d.b_rs == 1 && al(d.B, d.b_cs, d.b_b0, d.b_b1));
+#define MOPK_BG(AK, BN_) hipLaunchKernelGGL((bgemm_mfma_kernel<AK, BN_>), grid, dim3(256), 0, st, d, vecA, vecB)
+        if (akc && bnc) MOPK_BG(true, true); else if (akc) MOPK_BG(true, false);
+        else if (bnc) MOPK_BG(false, true); else MOPK_BG(false, false);
 #undef MOPK_BG
+    } else {
+#define MOPK_BG(AK, BN_) hipLaunchKernelGGL((bgemm_kernel<AK, BN_>), grid, dim3(256), 0, st, d)
+        if (akc && bnc) MOPK_BG(true, true); else if (akc) MOPK_BG(true, false);
+        else if (bnc) MOPK_BG(false, true); else MOPK_BG(false, false);
+#undef MOPK_BG
+    }
     MOPK_CHECK_LAUNCH();
     return MOPK_OK;
 }
