@@ -30,9 +30,9 @@ def run(gate_mode, use_k3, B=256):
     fwd = timed(infer)
     path = ops.LAST_PATH["edgewise_fwd"]
     line = f"{gate_mode:8s} {'k3' if use_k3 else '  '} B={B}: train step {step:7.1f} ms | inference fwd {fwd:6.2f} ms (path {path})"
-    if gate_mode == "dense" and not use_k3:
+    if not use_k3:
         ops.set_path("generic")
-        line += f" | generic inference fwd {timed(infer):6.2f} ms"
+        line += f" | generic path: train step {timed(lambda: m(x).backward(w), 3):6.1f} ms, inference fwd {timed(infer):6.2f} ms"
         ops.set_path("auto")
     print(line + f" | peak mem {torch.cuda.max_memory_allocated() / 1e9:.1f} GB", flush=True)
 
