@@ -268,38 +268,86 @@ __device__ __forceinline__ float edge_feat(const EwDims &d, const EwSaved &s, in
     if (c == 2 * d.V + 1) return s.Cl[o];
     return s.Lz[(c - 2 * d.V - 2) * nn + o];
 }
+// The two per-edge kernels that read planes transposed (S_v(j,i) as a feature, dX1(j,i) for its gradient) work on PAIRS of 16 x 16
+// tiles {(ti,tj), (tj,ti)}: both tiles of every plane are staged in LDS with row-contiguous loads, and each tile's transposed
+// operand is the other tile read with swapped indices (a per-pixel transposed read touches one 4-byte word per cache line).
+constexpr int TP = 16;
+__device__ __forceinline__ void pair_tiles(int pidx, int nt, int &ti, int &tj) {      // pair index -> ti <= tj, row-major over the upper triangle
+    int rrow = 0;
+    while (pidx >= nt - rrow) { pidx -= nt - rrow; ++rrow; }
+    ti = rrow; tj = rrow + pidx;
+}
+inline dim3 pair_grid(int N, int BH) { const int nt = (N + TP - 1) / TP; return dim3(nt * (nt + 1) / 2, BH); }
+// planes[v] tile (r0.., c0..) -> T[v][lr][lc] (zero outside the map)
+__device__ __forceinline__ void stage_tile(float (*T)[TP][TP + 1], const float *planes, int nplanes, int64_t nn, int64_t base, int LD, int N, int r0, int c0) {
+    const int lr = threadIdx.x / TP, lc = threadIdx.x % TP, i = r0 + lr, j = c0 + lc;
+    const bool ok = i < N && j < N;
+    for (int v = 0; v < nplanes; ++v) T[v][lr][lc] = ok ? planes[v * nn + base + (int64_t)i * LD + j] : 0.f;
+}
 // conv1 (1x1, C->16) + GELU [+ GELU for use_k3, :315-316]; without k3 also conv2 + sigmoid   :312-318
-__global__ void dense_gate_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= d.N * d.N) return;
-    const int i = p / d.N, j = p % d.N;
-    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
-    float f[MAXC], h[HID];
-    for (int c = 0; c < d.C; ++c) f[c] = edge_feat(d, s, c, bh, i, j);
-    for (int k = 0; k < HID; ++k) {
-        float x = e.b1[k];
-        for (int c = 0; c < d.C; ++c) x = fmaf(e.W1[k * d.C + c], f[c], x);
-        s.X1[k * nn + o] = x;
-        h[k] = gelu_tanh(x);
-    }
-    if (d.k3) {
-        for (int k = 0; k < HID; ++k) s.H2[k * nn + o] = gelu_tanh(h[k]);
-    } else {
-        for (int g = 0; g < 4; ++g) {
-            float z = e.b2[g];
-            for (int k = 0; k < HID; ++k) z = fmaf(e.W2[g * HID + k], h[k], z);
-            s.G[g * nn + o] = sigmoidf_(z);
+__global__ __launch_bounds__(TP * TP) void dense_gate_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
+    __shared__ float Ta[MAXV][TP][TP + 1], Tb[MAXV][TP][TP + 1];
+    __shared__ __attribute__((aligned(16))) float Ws[(MAXC + 1) * HID + 4 * HID + 4];   // W1^T [c][k] | b1 [k] | W2^T [k][g] | b2 [g]: uniform 16-byte LDS reads
+    for (int t = threadIdx.x; t < HID * d.C; t += TP * TP) Ws[(t % d.C) * HID + t / d.C] = e.W1[t];
+    if (threadIdx.x < HID) Ws[MAXC * HID + threadIdx.x] = e.b1[threadIdx.x];
+    if (threadIdx.x < 4 * HID) Ws[(MAXC + 1) * HID + (threadIdx.x % HID) * 4 + threadIdx.x / HID] = e.W2[threadIdx.x];
+    if (threadIdx.x < 4) Ws[(MAXC + 1) * HID + 4 * HID + threadIdx.x] = e.b2[threadIdx.x];
+    int ti, tj;
+    pair_tiles(blockIdx.x, (d.N + TP - 1) / TP, ti, tj);
+    const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl;
+    stage_tile(Ta, s.S, d.V, nn, bh * pl, d.LD, d.N, ti * TP, tj * TP);
+    if (ti != tj) stage_tile(Tb, s.S, d.V, nn, bh * pl, d.LD, d.N, tj * TP, ti * TP);
+    __syncthreads();
+    const int lr = threadIdx.x / TP, lc = threadIdx.x % TP;
+    for (int side = 0; side < (ti != tj ? 2 : 1); ++side) {
+        const int i = (side ? tj : ti) * TP + lr, j = (side ? ti : tj) * TP + lc;
+        if (i >= d.N || j >= d.N) continue;
+        float (*Td)[TP][TP + 1] = side ? Tb : Ta, (*Tt)[TP][TP + 1] = (ti == tj) ? Ta : (side ? Ta : Tb);
+        const int64_t o = bh * pl + (int64_t)i * d.LD + j;
+        float x[HID], h[HID];
+        for (int k4 = 0; k4 < HID / 4; ++k4) { const float4 b = *(const float4 *)&Ws[MAXC * HID + 4 * k4]; x[4 * k4] = b.x; x[4 * k4 + 1] = b.y; x[4 * k4 + 2] = b.z; x[4 * k4 + 3] = b.w; }
+        for (int c = 0; c < d.C; ++c) {
+            const float f = c < d.V ? Td[c][lr][lc] : c < 2 * d.V ? Tt[c - d.V][lc][lr] : edge_feat(d, s, c, bh, i, j);
+#pragma unroll
+            for (int k4 = 0; k4 < HID / 4; ++k4) {
+                const float4 wv = *(const float4 *)&Ws[c * HID + 4 * k4];
+                x[4 * k4] = fmaf(wv.x, f, x[4 * k4]); x[4 * k4 + 1] = fmaf(wv.y, f, x[4 * k4 + 1]);
+                x[4 * k4 + 2] = fmaf(wv.z, f, x[4 * k4 + 2]); x[4 * k4 + 3] = fmaf(wv.w, f, x[4 * k4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < HID; ++k) { s.X1[k * nn + o] = x[k]; h[k] = gelu_tanh(x[k]); }
+        if (d.k3) {
+#pragma unroll
+            for (int k = 0; k < HID; ++k) s.H2[k * nn + o] = gelu_tanh(h[k]);
+        } else {
+            const float4 b2 = *(const float4 *)&Ws[(MAXC + 1) * HID + 4 * HID];
+            float z[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+            for (int k = 0; k < HID; ++k) {
+                const float4 wv = *(const float4 *)&Ws[(MAXC + 1) * HID + 4 * k];
+                z[0] = fmaf(wv.x, h[k], z[0]); z[1] = fmaf(wv.y, h[k], z[1]); z[2] = fmaf(wv.z, h[k], z[2]); z[3] = fmaf(wv.w, h[k], z[3]);
+            }
+            for (int g = 0; g < 4; ++g) s.G[g * nn + o] = sigmoidf_(z[g]);
         }
     }
 }
-// use_k3: mid3 (3x3, 16->16, pad 1) on H2, then conv2 + sigmoid
-__global__ void dense_k3_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
+// use_k3: mid3 (3x3, 16->16, pad 1) on H2, then conv2 + sigmoid.  Weights sit in LDS as [(c, tap)][k]: per input value four uniform
+// 16-byte reads feed 16 independent FMA chains (as scalar loads of W3[k][c][tap] the kernel was bound by the scalar-memory latency)
+__global__ __launch_bounds__(256) void dense_k3_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
+    __shared__ __attribute__((aligned(16))) float W3s[HID * 9 * HID + HID + 4 * HID + 4];   // W3 [(c*9+tap)][k] | b3 | W2^T [k][g] | b2
+    for (int t = threadIdx.x; t < HID * HID * 9; t += 256) { const int k = t / (HID * 9), ct = t % (HID * 9); W3s[ct * HID + k] = e.W3[t]; }
+    if (threadIdx.x < HID) W3s[HID * 9 * HID + threadIdx.x] = e.b3[threadIdx.x];
+    if (threadIdx.x < 4 * HID) W3s[HID * 9 * HID + HID + (threadIdx.x % HID) * 4 + threadIdx.x / HID] = e.W2[threadIdx.x];
+    if (threadIdx.x < 4) W3s[HID * 9 * HID + HID + 4 * HID + threadIdx.x] = e.b2[threadIdx.x];
+    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.N * d.N) return;
     const int i = p / d.N, j = p % d.N;
     const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
     float x3[HID];
-    for (int k = 0; k < HID; ++k) x3[k] = e.b3[k];
+#pragma unroll
+    for (int k = 0; k < HID; ++k) x3[k] = W3s[HID * 9 * HID + k];
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) {
             const int ii = i + a - 1, jj = j + b - 1;
@@ -307,15 +355,26 @@ __global__ void dense_k3_fwd_kernel(EwDims d, EwSaved s, EwExt e) {
             const int64_t q = bh * pl + (int64_t)ii * d.LD + jj;
             for (int c = 0; c < HID; ++c) {
                 const float hv = s.H2[c * nn + q];
-                for (int k = 0; k < HID; ++k) x3[k] = fmaf(e.W3[((k * HID + c) * 3 + a) * 3 + b], hv, x3[k]);
+                const float4 *wr = (const float4 *)&W3s[(c * 9 + a * 3 + b) * HID];
+#pragma unroll
+                for (int k4 = 0; k4 < HID / 4; ++k4) {
+                    const float4 wv = wr[k4];
+                    x3[4 * k4] = fmaf(wv.x, hv, x3[4 * k4]); x3[4 * k4 + 1] = fmaf(wv.y, hv, x3[4 * k4 + 1]);
+                    x3[4 * k4 + 2] = fmaf(wv.z, hv, x3[4 * k4 + 2]); x3[4 * k4 + 3] = fmaf(wv.w, hv, x3[4 * k4 + 3]);
+                }
             }
         }
+#pragma unroll
     for (int k = 0; k < HID; ++k) s.X3[k * nn + o] = x3[k];
-    for (int g = 0; g < 4; ++g) {
-        float z = e.b2[g];
-        for (int k = 0; k < HID; ++k) z = fmaf(e.W2[g * HID + k], x3[k], z);
-        s.G[g * nn + o] = sigmoidf_(z);
+    const float *w2 = &W3s[HID * 9 * HID + HID];
+    const float4 b2 = *(const float4 *)&w2[4 * HID];
+    float z[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+    for (int k = 0; k < HID; ++k) {
+        const float4 wv = *(const float4 *)&w2[4 * k];
+        z[0] = fmaf(wv.x, x3[k], z[0]); z[1] = fmaf(wv.y, x3[k], z[1]); z[2] = fmaf(wv.z, x3[k], z[2]); z[3] = fmaf(wv.w, x3[k], z[3]);
     }
+    for (int g = 0; g < 4; ++g) s.G[g * nn + o] = sigmoidf_(z[g]);
 }
 
 struct RowGates { float a[4][MAXR]; };
@@ -606,13 +665,17 @@ __global__ void dense_bwd_last_kernel(EwDims d, EwSaved s, EwWork w, EwExt e) {
         else w.DX1[k * nn + o] = dl * gelu_tanh_grad(s.X1[k * nn + o]);
     }
 }
-// use_k3: dH2 = conv_transpose(dX3, W3) ; dX1 = dH2 * gelu'(gelu(X1)) * gelu'(X1)
-__global__ void dense_k3_bwd_kernel(EwDims d, EwSaved s, EwWork w, EwExt e) {
+// use_k3: dH2 = conv_transpose(dX3, W3) ; dX1 = dH2 * gelu'(gelu(X1)) * gelu'(X1).  Weights in LDS as [(k, tap)][c] (see dense_k3_fwd_kernel)
+__global__ __launch_bounds__(256) void dense_k3_bwd_kernel(EwDims d, EwSaved s, EwWork w, EwExt e) {
+    __shared__ __attribute__((aligned(16))) float W3s[HID * 9 * HID];
+    for (int t = threadIdx.x; t < HID * HID * 9; t += 256) { const int k = t / (HID * 9), c = (t / 9) % HID, tap = t % 9; W3s[(k * 9 + tap) * HID + c] = e.W3[t]; }
+    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.N * d.N) return;
     const int i = p / d.N, j = p % d.N;
     const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl, o = bh * pl + (int64_t)i * d.LD + j;
     float dh[HID];
+#pragma unroll
     for (int c = 0; c < HID; ++c) dh[c] = 0.f;
     for (int a = 0; a < 3; ++a)
         for (int b = 0; b < 3; ++b) {
@@ -621,35 +684,51 @@ __global__ void dense_k3_bwd_kernel(EwDims d, EwSaved s, EwWork w, EwExt e) {
             const int64_t q = bh * pl + (int64_t)ii * d.LD + jj;
             for (int k = 0; k < HID; ++k) {
                 const float g = w.DX3[k * nn + q];
-                for (int c = 0; c < HID; ++c) dh[c] = fmaf(e.W3[((k * HID + c) * 3 + a) * 3 + b], g, dh[c]);
+                const float4 *wr = (const float4 *)&W3s[(k * 9 + a * 3 + b) * HID];
+#pragma unroll
+                for (int c4 = 0; c4 < HID / 4; ++c4) {
+                    const float4 wv = wr[c4];
+                    dh[4 * c4] = fmaf(wv.x, g, dh[4 * c4]); dh[4 * c4 + 1] = fmaf(wv.y, g, dh[4 * c4 + 1]);
+                    dh[4 * c4 + 2] = fmaf(wv.z, g, dh[4 * c4 + 2]); dh[4 * c4 + 3] = fmaf(wv.w, g, dh[4 * c4 + 3]);
+                }
             }
         }
+#pragma unroll
     for (int c = 0; c < HID; ++c) {
         const float x1 = s.X1[c * nn + o];
         w.DX1[c * nn + o] = dh[c] * gelu_tanh_grad(gelu_tanh(x1)) * gelu_tanh_grad(x1);
     }
 }
-// d feat = W1^T dX1 scattered to its sources: S_v(i,j), S_v(j,i) (transposed read), Cr, Cl, lens planes
-__global__ void dense_bwd_feat_kernel(EwDims d, EwWork w, EwExt e) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= d.N * d.N) return;
-    const int i = p / d.N, j = p % d.N;
+// d feat = W1^T dX1 scattered to its sources: S_v(i,j), S_v(j,i) (dX1 of the transposed edge: tile pairs, see above), Cr, Cl, lens planes
+__global__ __launch_bounds__(TP * TP) void dense_bwd_feat_kernel(EwDims d, EwWork w, EwExt e) {
+    __shared__ float Ta[HID][TP][TP + 1], Tb[HID][TP][TP + 1];
+    int ti, tj;
+    pair_tiles(blockIdx.x, (d.N + TP - 1) / TP, ti, tj);
     const int64_t bh = blockIdx.y, pl = (int64_t)d.N * d.LD, nn = d.BH * pl;
-    const int64_t o = bh * pl + (int64_t)i * d.LD + j, ot = bh * pl + (int64_t)j * d.LD + i;
-    float g1[HID], g2[HID];
-    for (int k = 0; k < HID; ++k) { g1[k] = w.DX1[k * nn + o]; g2[k] = w.DX1[k * nn + ot]; }
-    for (int v = 0; v < d.V; ++v) {
-        float t = 0.f;
-        for (int k = 0; k < HID; ++k) t = fmaf(e.W1[k * d.C + v], g1[k], fmaf(e.W1[k * d.C + d.V + v], g2[k], t));
-        w.dSf[v * nn + o] = t;
-    }
-    float tr = 0.f, tl = 0.f;
-    for (int k = 0; k < HID; ++k) { tr = fmaf(e.W1[k * d.C + 2 * d.V], g1[k], tr); tl = fmaf(e.W1[k * d.C + 2 * d.V + 1], g1[k], tl); }
-    w.dCrf[o] = tr; w.dClf[o] = tl;
-    for (int lv = 0; lv < d.L * d.V; ++lv) {
-        float t = 0.f;
-        for (int k = 0; k < HID; ++k) t = fmaf(e.W1[k * d.C + 2 * d.V + 2 + lv], g1[k], t);
-        w.dLz[lv * nn + o] = t;
+    stage_tile(Ta, w.DX1, HID, nn, bh * pl, d.LD, d.N, ti * TP, tj * TP);
+    if (ti != tj) stage_tile(Tb, w.DX1, HID, nn, bh * pl, d.LD, d.N, tj * TP, ti * TP);
+    __syncthreads();
+    const int lr = threadIdx.x / TP, lc = threadIdx.x % TP;
+    for (int side = 0; side < (ti != tj ? 2 : 1); ++side) {
+        const int i = (side ? tj : ti) * TP + lr, j = (side ? ti : tj) * TP + lc;
+        if (i >= d.N || j >= d.N) continue;
+        float (*Td)[TP][TP + 1] = side ? Tb : Ta, (*Tt)[TP][TP + 1] = (ti == tj) ? Ta : (side ? Ta : Tb);
+        const int64_t o = bh * pl + (int64_t)i * d.LD + j;
+        float g1[HID], g2[HID];
+        for (int k = 0; k < HID; ++k) { g1[k] = Td[k][lr][lc]; g2[k] = Tt[k][lc][lr]; }
+        for (int v = 0; v < d.V; ++v) {
+            float t = 0.f;
+            for (int k = 0; k < HID; ++k) t = fmaf(e.W1[k * d.C + v], g1[k], fmaf(e.W1[k * d.C + d.V + v], g2[k], t));
+            w.dSf[v * nn + o] = t;
+        }
+        float tr = 0.f, tl = 0.f;
+        for (int k = 0; k < HID; ++k) { tr = fmaf(e.W1[k * d.C + 2 * d.V], g1[k], tr); tl = fmaf(e.W1[k * d.C + 2 * d.V + 1], g1[k], tl); }
+        w.dCrf[o] = tr; w.dClf[o] = tl;
+        for (int lv = 0; lv < d.L * d.V; ++lv) {
+            float t = 0.f;
+            for (int k = 0; k < HID; ++k) t = fmaf(e.W1[k * d.C + 2 * d.V + 2 + lv], g1[k], t);
+            w.dLz[lv * nn + o] = t;
+        }
     }
 }
 // low-rank head + lens bank: the head only saw the planes' means -> dLz(i,j) = (drL_i + dcL_j) / N
@@ -989,7 +1068,7 @@ static int ew_generic_fwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
         }
     }
     if (d.dense) {                                                                                                    // :312-318
-        hipLaunchKernelGGL(dense_gate_fwd_kernel, pix, dim3(256), 0, st, d, s, e);
+        hipLaunchKernelGGL(dense_gate_fwd_kernel, pair_grid(d.N, (int)d.BH), dim3(TP * TP), 0, st, d, s, e);
         if (d.k3) hipLaunchKernelGGL(dense_k3_fwd_kernel, pix, dim3(256), 0, st, d, s, e);
     } else {
         hipLaunchKernelGGL(gate_ab_kernel, dim3((rows1 + 255) / 256), dim3(256), 0, st, *a, d, s);                    // :325-326
@@ -1047,7 +1126,7 @@ static int ew_generic_bwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
     if (d.dense) {
         hipLaunchKernelGGL(dense_bwd_last_kernel, pix, dim3(256), 0, st, d, s, w, e);
         if (d.k3) hipLaunchKernelGGL(dense_k3_bwd_kernel, pix, dim3(256), 0, st, d, s, w, e);
-        hipLaunchKernelGGL(dense_bwd_feat_kernel, pix, dim3(256), 0, st, d, w, e);
+        hipLaunchKernelGGL(dense_bwd_feat_kernel, pair_grid(N, BHi), dim3(TP * TP), 0, st, d, w, e);
         MOPK_CHECK_LAUNCH();
         // weight gradients: all-pairs pixel reductions, partials per block then a fixed-order sum (bit-reproducible)
         const int strips = (N + PR_PS - 1) / PR_PS, pc = ((N + strips - 1) / strips + 3) & ~3;   // N=197: 4 strips of 52
