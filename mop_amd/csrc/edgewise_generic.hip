@@ -816,7 +816,11 @@ struct LdLast1 {           // input of conv2: X3 (use_k3) or gelu(X1); then the 
 constexpr int PR_PS = 64, PR_LDS = PR_PS + 4;        // pixels per tile; LDS row stride (fragment reads touch all 64 banks)
 struct PrTile { int64_t bh; int i, j0, jn; };
 __device__ inline PrTile pr_tile(const EwDims &d, int64_t tile, int pc, int strips) {
-    const int64_t row = tile / strips, bh = row / d.N;
+    int64_t row, bh;
+    if (tile < (1ll << 31)) {                 // the usual case: 32-bit divisions (a 64-bit one is a ~200-instruction routine, per tile)
+        const unsigned int r32 = (unsigned int)tile / (unsigned int)strips;
+        row = r32; bh = r32 / (unsigned int)d.N;
+    } else { row = tile / strips; bh = row / d.N; }
     const int strip = (int)(tile - row * strips), j0 = strip * pc;
     return PrTile{bh, (int)(row - bh * d.N), j0, min(pc, d.N - j0)};
 }
@@ -891,7 +895,8 @@ __global__ __launch_bounds__(256) void taps_reduce_kernel(EwDims d, const float 
     const int64_t tiles = d.BH * d.N * strips;
     int boff[TR_NT];
     f32x4 acc[TR_NT];
-    float va[TR_AIT], vh[TR_HIT];
+    struct Regs { float va[TR_AIT], vh[TR_HIT]; int jn; };
+    Regs R0, R1;                             // two tiles in flight: a tile's loads have two iterations (~2.5 k cycles of MFMAs) to land
 #pragma unroll
     for (int t = 0; t < TR_NT; ++t) {
         const int b = 16 * t + lr, c = b / 9, tap = b % 9;
@@ -899,44 +904,71 @@ __global__ __launch_bounds__(256) void taps_reduce_kernel(EwDims d, const float 
         acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int idx = tid; idx < TR_STAGE; idx += 256) S[idx] = idx >= TR_ONE && idx < TR_ZERO ? 1.f : 0.f;
-    auto fetch = [&](const PrTile &t) {
-        const float *x3 = X3 + (t.bh * d.N + t.i) * (int64_t)d.LD + t.j0, *h2 = H2 + t.bh * d.N * (int64_t)d.LD;
+    // per-thread constants of the staging pattern: element (channel, row offset, pixel) of slot `it` does not depend on the tile
+    int64_t offa[TR_AIT], offh[TR_HIT];
+    int ppa[TR_AIT], pph[TR_HIT], drh[TR_HIT];
 #pragma unroll
-        for (int it = 0; it < TR_AIT; ++it) {
-            const int idx = tid + 256 * it, ch = idx / PR_PS, pp = idx % PR_PS;
-            va[it] = pp < t.jn ? x3[ch * nn + pp] : 0.f;
-        }
+    for (int it = 0; it < TR_AIT; ++it) { const int idx = tid + 256 * it; ppa[it] = idx % PR_PS; offa[it] = (idx / PR_PS) * nn + ppa[it]; }
+#pragma unroll
+    for (int it = 0; it < TR_HIT; ++it) {
+        const int idx = tid + 256 * it, cr = idx / TR_HW;
+        pph[it] = cr < HID * 3 ? idx % TR_HW : 1 << 20;              // slots past the 48 rows never pass the bounds test
+        drh[it] = cr % 3 - 1;
+        offh[it] = (cr / 3) * nn + (int64_t)drh[it] * d.LD + pph[it] - 1;
+    }
+    auto fetch = [&](Regs &R, int64_t tile) {
+        const PrTile t = pr_tile(d, tile, pc, strips);
+        R.jn = t.jn;
+        const float *x3 = X3 + (t.bh * d.N + t.i) * (int64_t)d.LD + t.j0, *h2 = H2 + (t.bh * d.N + t.i) * (int64_t)d.LD + t.j0;
+#pragma unroll
+        for (int it = 0; it < TR_AIT; ++it) R.va[it] = ppa[it] < t.jn ? x3[offa[it]] : 0.f;
 #pragma unroll
         for (int it = 0; it < TR_HIT; ++it) {
-            const int idx = tid + 256 * it, cr = idx / TR_HW, pp = idx % TR_HW, c = cr / 3, ii = t.i + cr % 3 - 1, jj = t.j0 + pp - 1;
-            vh[it] = 0.f;
-            if (cr < HID * 3 && pp < t.jn + 2 && ii >= 0 && ii < d.N && jj >= 0 && jj < d.N) vh[it] = h2[c * nn + (int64_t)ii * d.LD + jj];
+            const int ii = t.i + drh[it], jj = t.j0 + pph[it] - 1;
+            R.vh[it] = 0.f;
+            if (pph[it] < t.jn + 2 && ii >= 0 && ii < d.N && jj >= 0 && jj < d.N) R.vh[it] = h2[offh[it]];
         }
     };
-    int64_t tile = blockIdx.x;
-    PrTile cur = pr_tile(d, tile < tiles ? tile : 0, pc, strips);
-    if (tile < tiles) fetch(cur);
-    __syncthreads();
-    for (; tile < tiles; tile += gridDim.x) {
+    // one tile: registers -> LDS, barrier, refill the registers with the tile two steps ahead, MFMAs, barrier
+    auto step = [&](Regs &R, int64_t ahead) {
 #pragma unroll
         for (int it = 0; it < TR_AIT; ++it) {
             const int idx = tid + 256 * it;
-            S[TR_A + (idx / PR_PS) * PR_LDS + idx % PR_PS] = va[it];
+            S[TR_A + (idx / PR_PS) * PR_LDS + idx % PR_PS] = R.va[it];
         }
 #pragma unroll
         for (int it = 0; it < TR_HIT; ++it) {
             const int idx = tid + 256 * it, cr = idx / TR_HW;
-            if (cr < HID * 3) S[TR_H + cr * PR_LDS + idx % TR_HW] = vh[it];
+            if (cr < HID * 3) S[TR_H + cr * PR_LDS + idx % TR_HW] = R.vh[it];
         }
         __syncthreads();
-        const int jn = cur.jn;
-        if (tile + gridDim.x < tiles) { cur = pr_tile(d, tile + gridDim.x, pc, strips); fetch(cur); }
-        for (int k = w; 4 * k < jn; k += 4) {
+        const int jn = R.jn;
+        if (ahead < tiles) fetch(R, ahead);
+        // k-steps w, w + 4, w + 8 unconditionally (pixels past jn are staged as zeros), w + 12 when the strip is that long: straight-line
+        // code, so the LDS reads of a later step are in flight under the MFMAs of an earlier one
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int k = w + 4 * u;
+            const float av = S[TR_A + lr * PR_LDS + 4 * k + lq];
+#pragma unroll
+            for (int t = 0; t < TR_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, S[boff[t] + 4 * k], acc[t], 0, 0, 0);
+        }
+        if (4 * (w + 12) < jn) {
+            const int k = w + 12;
             const float av = S[TR_A + lr * PR_LDS + 4 * k + lq];
 #pragma unroll
             for (int t = 0; t < TR_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, S[boff[t] + 4 * k], acc[t], 0, 0, 0);
         }
         __syncthreads();
+    };
+    const int64_t g = gridDim.x;
+    int64_t tile = blockIdx.x;
+    if (tile < tiles) fetch(R0, tile);
+    if (tile + g < tiles) fetch(R1, tile + g);
+    __syncthreads();
+    for (; tile < tiles; tile += 2 * g) {
+        step(R0, tile + 2 * g);
+        if (tile + g < tiles) step(R1, tile + 3 * g);
     }
     pr_finish<TR_NT>(S, acc, HID, HID * 9 + 1, part);
 }
