@@ -378,14 +378,21 @@ __global__ __launch_bounds__(256) void dense_k3_fwd_kernel(EwDims d, EwSaved s, 
 }
 
 struct RowGates { float a[4][MAXR]; };
+// (loops over the rank are unrolled to MAXR with a `k < r` guard: with a runtime trip count the small arrays are indexed dynamically
+//  and live in scratch memory -- 16 scratch loads per edge in the kernels below)
 __device__ __forceinline__ void load_row_gates(RowGates &g, const float *ga_bh, int r, int N, int i) {
+#pragma unroll
     for (int q = 0; q < 4; ++q)
+#pragma unroll
         for (int k = 0; k < MAXR; ++k) g.a[q][k] = k < r ? ga_bh[(q * r + k) * N + i] : 0.f;
 }
 __device__ __forceinline__ void gates_at(float G[4], const RowGates &g, const float *gb_bh, int r, int N, int j) {
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         float z = 0.f;
-        for (int k = 0; k < r; ++k) z = fmaf(g.a[q][k], gb_bh[(q * r + k) * N + j], z);
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < r) z = fmaf(g.a[q][k], gb_bh[(q * r + k) * N + j], z);
         G[q] = sigmoidf_(z);
     }
 }
@@ -495,7 +502,10 @@ __global__ void mix_bwd_rows_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwW
     const int64_t vstride = d.BH * (int64_t)d.N * d.LD;
     const float nb = a.beta_not / (float)max(1, d.V - 1);
     float da[4][MAXR];
-    for (int q = 0; q < 4; ++q) for (int k = 0; k < MAXR; ++k) da[q][k] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) da[q][k] = 0.f;
     for (int j = lane; j < d.N; j += 64) {
         const float dsm = P[j] * (dP[j] - dot);
         dP[j] = dsm;
@@ -503,18 +513,26 @@ __global__ void mix_bwd_rows_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwW
         view_stats(s.S, vstride, row * d.LD + j, d.V, sv, O, lse);
         edge_gates(G, d, s, rg, gb, row, j);
         gate_terms(tg, sv, O, lse, nb, s.Cr[row * d.LD + j]);
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float dz = dsm * tg[q] * G[q] * (1.f - G[q]);
             if (d.dense) w.dZ[q * vstride + row * d.LD + j] = dz;      // dense head: the pre-sigmoid gradient map goes to the head's backward
-            else for (int k = 0; k < d.r; ++k) da[q][k] = fmaf(dz, gb[(q * d.r + k) * d.N + j], da[q][k]);
+            else {
+#pragma unroll
+                for (int k = 0; k < MAXR; ++k)
+                    if (k < d.r) da[q][k] = fmaf(dz, gb[(q * d.r + k) * d.N + j], da[q][k]);
+            }
         }
     }
     if (d.dense) return;
+#pragma unroll
     for (int q = 0; q < 4; ++q)
-        for (int k = 0; k < d.r; ++k) {
-            const float v = wave_sum(da[q][k]);
-            if (lane == 0) w.da[(bh * 4 * d.r + q * d.r + k) * d.N + i] = v;
-        }
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < d.r) {
+                const float v = wave_sum(da[q][k]);
+                if (lane == 0) w.da[(bh * 4 * d.r + q * d.r + k) * d.N + i] = v;
+            }
 }
 // thread per (bh,j): db[g,k,j] = sum_i dZ_g[i,j] a[g,k,i]
 __global__ void mix_bwd_cols_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwWork w) {
@@ -523,7 +541,10 @@ __global__ void mix_bwd_cols_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwW
     if (j >= d.N) return;
     const float *ga = s.ga + bh * 4 * d.r * d.N, *gb = s.gb + bh * 4 * d.r * d.N;
     float bj[4][MAXR], db[4][MAXR];
-    for (int q = 0; q < 4; ++q) for (int k = 0; k < MAXR; ++k) { bj[q][k] = k < d.r ? gb[(q * d.r + k) * d.N + j] : 0.f; db[q][k] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k) { bj[q][k] = k < d.r ? gb[(q * d.r + k) * d.N + j] : 0.f; db[q][k] = 0.f; }
     const int64_t vstride = d.BH * (int64_t)d.N * d.LD;
     const float nb = a.beta_not / (float)max(1, d.V - 1);
     for (int i = 0; i < d.N; ++i) {
@@ -532,15 +553,22 @@ __global__ void mix_bwd_cols_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwW
         float sv[MAXV], O, lse, tg[4];
         view_stats(s.S, vstride, off, d.V, sv, O, lse);
         gate_terms(tg, sv, O, lse, nb, s.Cr[off]);
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float z = 0.f;
-            for (int k = 0; k < d.r; ++k) z = fmaf(ga[(q * d.r + k) * d.N + i], bj[q][k], z);
+            float z = 0.f, av[MAXR];
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k) { av[k] = k < d.r ? ga[(q * d.r + k) * d.N + i] : 0.f; z = fmaf(av[k], bj[q][k], z); }
             const float G = sigmoidf_(z);
             const float dz = dsm * tg[q] * G * (1.f - G);
-            for (int k = 0; k < d.r; ++k) db[q][k] = fmaf(dz, ga[(q * d.r + k) * d.N + i], db[q][k]);
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k) db[q][k] = fmaf(dz, av[k], db[q][k]);
         }
     }
-    for (int q = 0; q < 4; ++q) for (int k = 0; k < d.r; ++k) w.db[(bh * 4 * d.r + q * d.r + k) * d.N + j] = db[q][k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+            if (k < d.r) w.db[(bh * 4 * d.r + q * d.r + k) * d.N + j] = db[q][k];
 }
 // thread per (bh,n): d row_feat = Wr^T da, d col_feat = Wc^T db -> gradients of the 2V+2 means
 __global__ void gate_ab_bwd_kernel(MopkEdgewiseArgs a, EwDims d, EwWork w) {
@@ -614,39 +642,44 @@ __global__ void dchain_seed_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwWo
         w.dCb[off] = (li + w.dcCl[bh * d.N + j] * invN) * expf(-s.Cl[off]);
     }
 }
-// wave per (v,bh,i): dS_v = A_v (dA_v - sum A_v dA_v) + dSmix coef_v + (drS_i + dcS_j)/N   (in place over dA)
+// wave per (bh,i), all views: dS_v = A_v (dA_v - sum A_v dA_v) + dSmix coef_v + (drS_i + dcS_j)/N   (in place over dA).  The per-edge
+// view statistics and gates are evaluated once and shared by the V views (one wave per (v,bh,i) evaluated them V times)
 __global__ void ds_final_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s, EwWork w) {
-    const int64_t grow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t rows_per_v = d.BH * d.N;
-    if (grow >= d.V * rows_per_v) return;
+    if (row >= rows_per_v) return;
     const int lane = threadIdx.x & 63;
-    const int v = grow / rows_per_v;
-    const int64_t row = grow % rows_per_v;
     const int i = row % d.N;
     const int64_t bh = row / d.N;
     const int64_t vstride = rows_per_v * d.LD;
-    const float *A = s.A + v * vstride + row * d.LD;
-    float *dA = w.dA + v * vstride + row * d.LD;
-    float dot = 0.f;
-    for (int j = lane; j < d.N; j += 64) dot += A[j] * dA[j];
-    dot = wave_sum(dot);
+    float dot[MAXV];
+    for (int v = 0; v < d.V; ++v) {
+        const float *A = s.A + v * vstride + row * d.LD;
+        const float *dA = w.dA + v * vstride + row * d.LD;
+        float t = 0.f;
+        for (int j = lane; j < d.N; j += 64) t += A[j] * dA[j];
+        dot[v] = wave_sum(t);
+    }
     RowGates rg;
     if (!d.dense) load_row_gates(rg, s.ga + bh * 4 * d.r * d.N, d.r, d.N, i);
     const float *gb = s.gb + bh * 4 * d.r * d.N;
     const float nb = a.beta_not / (float)max(1, d.V - 1);
     const float invN = 1.f / d.N;
-    const float ri = d.dense ? 0.f : w.drS[v * rows_per_v + row] * invN;
     const bool edge = d.dense || d.L > 0;            // gradients that reach S_v through per-edge features (dense head, lens bank)
     for (int j = lane; j < d.N; j += 64) {
         float sv[MAXV], O, lse, G[4];
         view_stats(s.S, vstride, row * d.LD + j, d.V, sv, O, lse);
         edge_gates(G, d, s, rg, gb, row, j);
-        const float pi = expf(sv[v] - lse);
-        const float coef = v == 0 ? (1.f - G[1] + G[1] * pi) : (G[0] - nb * G[2] + G[1] * pi);
-        float t = A[j] * (dA[j] - dot) + w.dP[row * d.LD + j] * coef + ri;
-        if (!d.dense) t += w.dcS[v * rows_per_v + bh * d.N + j] * invN;
-        if (edge) t += w.dSf[v * vstride + row * d.LD + j];
-        dA[j] = t;
+        const float dp = w.dP[row * d.LD + j];
+        for (int v = 0; v < d.V; ++v) {
+            const int64_t o = v * vstride + row * d.LD + j;
+            const float pi = expf(sv[v] - lse);
+            const float coef = v == 0 ? (1.f - G[1] + G[1] * pi) : (G[0] - nb * G[2] + G[1] * pi);
+            float t = s.A[o] * (w.dA[o] - dot[v]) + dp * coef + (d.dense ? 0.f : w.drS[v * rows_per_v + row] * invN);
+            if (!d.dense) t += w.dcS[v * rows_per_v + bh * d.N + j] * invN;
+            if (edge) t += w.dSf[o];
+            w.dA[o] = t;
+        }
     }
 }
 // ---- dense head backward (per pixel) ----
@@ -1215,7 +1248,7 @@ static int ew_generic_bwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
         hipLaunchKernelGGL(axpy_kernel, dim3((nnv + 255) / 256), dim3(256), 0, st, w.dA + first * nnv, D, nnv);
         MOPK_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(ds_final_kernel, dim3((rowsV + 3) / 4), dim3(256), 0, st, *a, d, s, w);
+    hipLaunchKernelGGL(ds_final_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, *a, d, s, w);
     MOPK_CHECK_LAUNCH();
     {
         GemmDesc g = gd(N, dk, N, V, BHi);           // dQe_v = dS_v K
