@@ -352,8 +352,10 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma unroll
             for (int j = 0; j < 8; ++j) { c[j] = bf2f((unsigned short)Xc[t][0][j]); c[8 + j] = bf2f((unsigned short)Xc[t][1][j]); }
             log_tile(c, t, rs);
+            if (!SAVE) {                  // with the record, the mix loop re-reads the C-> export instead (56 registers free through the <- chain)
 #pragma unroll
-            for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(c[2 * p], c[2 * p + 1]);
+                for (int p = 0; p < 8; ++p) crp[t][p] = pack_h2(c[2 * p], c[2 * p + 1]);
+            }
         }
         rs += __shfl_xor(rs, 32, 64);
         if (h == 0) rCr[qi] = rs * invN;
@@ -555,11 +557,22 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
 #pragma nounroll
     for (int t = 0; t < NT; ++t) {
         unsigned int cw[8];
+        if (SAVE) {                       // log C-> of this tile from the wave's own export: the same bf16 values, the same fp16 packing
+            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+            const u4 *cfp = (const u4 *)(svb + SL.oCF + (size_t)w * NT * 8 * 64 * 4) + lane;
+            const bf16x8 cl = __builtin_bit_cast(bf16x8, cfp[(2 * t) * 64]), ch = __builtin_bit_cast(bf16x8, cfp[(2 * t + 1) * 64]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                cw[p] = pack_h2(__logf(bf2f((unsigned short)cl[2 * p]) + EPSC), __logf(bf2f((unsigned short)cl[2 * p + 1]) + EPSC));
+                cw[4 + p] = pack_h2(__logf(bf2f((unsigned short)ch[2 * p]) + EPSC), __logf(bf2f((unsigned short)ch[2 * p + 1]) + EPSC));
+            }
+        } else {
         switch (t) {
 #define MOPK_CASE(T_) case T_: if (T_ < NT) { _Pragma("unroll") for (int p = 0; p < 8; ++p) cw[p] = crp[T_ < NT ? T_ : 0][p]; } break;
             MOPK_CASE(0) MOPK_CASE(1) MOPK_CASE(2) MOPK_CASE(3) MOPK_CASE(4) MOPK_CASE(5) MOPK_CASE(6)
 #undef MOPK_CASE
             default: break;
+        }
         }
         f32x16 S0, O, L;
         {
@@ -738,11 +751,13 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
                 __builtin_nontemporal_store(u4{cw[4], cw[5], cw[6], cw[7]}, &sp[(2 * t + 1) * 64]);
             }
         }
+        if (!SAVE) {
         switch (t) {
 #define MOPK_CASE(T_) case T_: if (T_ < NT) { _Pragma("unroll") for (int p = 0; p < 8; ++p) crp[T_ < NT ? T_ : 0][p] = cw[p]; } break;
             MOPK_CASE(0) MOPK_CASE(1) MOPK_CASE(2) MOPK_CASE(3) MOPK_CASE(4) MOPK_CASE(5) MOPK_CASE(6)
 #undef MOPK_CASE
             default: break;
+        }
         }
     }
     FSTAMP();
@@ -753,6 +768,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_fwd_kernel(MopkEdgewiseArgs 
     bf16x8 Pp[NT][2];
     const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);      // attn_drop (:552): keep / (1 - p) on P; the row sum stays undropped
     const uint32_t rowh = fa_drop_row(drop, b * H + hh, qi);
+    if (SAVE) {                           // Smix back from the wave's own S_SM export (L2-hot) rather than 56 registers held through the mix loop
+        typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+        const u4 *sp = (const u4 *)(svb + SL.oSm + (size_t)w * NT * 8 * 64 * 4) + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const u4 lo = sp[(2 * t) * 64], hi = sp[(2 * t + 1) * 64];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { crp[t][p] = lo[p]; crp[t][4 + p] = hi[p]; }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
