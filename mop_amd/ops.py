@@ -380,12 +380,20 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
                 g["W3"], g["b3"], g["lens_w"], None, None, None, None, None, None, None)
 
 
+def _empty_batch(t: torch.Tensor, *shape) -> torch.Tensor:
+    """B = 0: the reference's torch ops return an empty result; the C ABI rejects empty shapes.  An empty tensor that still hangs
+    on `t` in the autograd graph (its backward hands `t` an empty gradient)."""
+    return t.new_zeros(shape) + t.sum() * 0
+
+
 def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float, n_views: int, variant: EdgewiseVariant,
                           W3=None, b3=None, lens_w=None, precision: Optional[int] = None, dropout_p: float = 0.0,
                           seed: Optional[int] = None, attn_mask=None):
     """EdgewiseMSA core for the dense gate head and/or the S lens bank.  head = (Wr, br, Wc, bc) for the low-rank head
     with C = 2V+2+L*V input channels, or (W1 (16,C), b1, W2 (4,16), b2) for the dense head; W3/b3 with use_k3;
     lens_w (L,V,3,3).  qkv as in edgewise_lowrank_core."""
+    if qkv.shape[0] == 0:
+        return _empty_batch(qkv, 0, qkv.shape[1], qkv.shape[-2] * qkv.shape[-1])
     prec = _prec_for(qkv.dtype) if precision is None else precision
     e = qkv.new_zeros(0, dtype=torch.float32)
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
@@ -401,6 +409,8 @@ def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_
                           dropout_p: float = 0.0, seed: Optional[int] = None):
     """qkv: (B,N,Vq,3,H,dk) with Vq in {1 (share_qkv), n_views}; returns (B,N,H*dk).  dropout_p > 0: attn_drop on the mixed
     attention weights (:552) inside the fused kernels (see `sdpa_core`)."""
+    if qkv.shape[0] == 0:
+        return _empty_batch(qkv, 0, qkv.shape[1], qkv.shape[-2] * qkv.shape[-1])
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     prec = _prec_for(qkv.dtype) if precision is None else precision
     want_bwd = torch.is_grad_enabled() and any(
@@ -536,6 +546,8 @@ def dropout_keep_mask(seed: int, p: float, B: int, H: int, N: int) -> torch.Tens
 def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
     """q,k,v: (B,N,H,dk) views. Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive.  dropout_p > 0: the probabilities
     are multiplied by keep / (1 - p) inside the fused kernels (mask = `dropout_keep_mask(seed, ...)`, seed drawn when None)."""
+    if q.shape[0] == 0:
+        return _empty_batch(q, 0, q.shape[1], q.shape[2] * q.shape[3]) + (k.sum() + v.sum()) * 0
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype), _PATH, drop)
 
@@ -608,6 +620,8 @@ class _CrossViewFn(torch.autograd.Function):
 def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, anchor_mode="argmax_row_sum", fixed_k_star=0,
                    attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
     """q*,k*,v1: (B,N,H,dk) views; mix (2,2).  prior_weight = 0 disables the per-key prior.  Returns (B,N,H*dk)."""
+    if q1.shape[0] == 0:
+        return _empty_batch(q1, 0, q1.shape[1], q1.shape[2] * q1.shape[3])
     prec = _prec_for(q1.dtype)
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     if (prior_weight <= 0.0 and t1 == 0.0 and t2 == 0.0 and attn_mask is None and _PATH != L.PATH_GENERIC and prec == L.PREC_BF16
@@ -699,6 +713,8 @@ class _DualPathFn(torch.autograd.Function):
 
 def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_chain, beta_not, hops,
                   attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
+    if q1.shape[0] == 0:
+        return _empty_batch(q1, 0, q1.shape[1], q1.shape[2] * q1.shape[3])
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     return _DualPathFn.apply(q1, k1, v1, q2, k2, v2, chain_logit, (g_and, g_or, g_not, g_chain), beta_not,
                              int(hops), attn_mask, causal, _prec_for(q1.dtype), _PATH, drop)
@@ -791,6 +807,9 @@ class _QuartetFn(torch.autograd.Function):
 
 def quartet_core(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights=False,
                  dropout_p: float = 0.0, seed: Optional[int] = None):
+    if q.shape[0] == 0:                   # q: (B,T,H,dk)
+        out = _empty_batch(q, 0, q.shape[1], q.shape[2] * q.shape[3])
+        return (out, q.new_zeros((0, q.shape[2], q.shape[1], q.shape[1]), dtype=torch.float32)) if need_weights else out
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     return _QuartetFn.apply(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights,
                             _prec_for(q.dtype), _PATH, drop)

@@ -572,3 +572,19 @@ def test_sdpa_vs_oracle_at_whisper_sequence_length():
     assert max_abs(hp(y.view(B, T, H, dk)), yo) <= 1e-2
     for got, ref, nm in ((tg[0].grad, g["dq"], "dq"), (tg[1].grad, g["dk"], "dk"), (tg[2].grad, g["dv"], "dv")):
         assert rel_err(hp(got), ref) <= 3e-2, f"{nm} {rel_err(hp(got), ref):.3e}"
+
+
+def test_empty_batch_returns_an_empty_result_like_the_torch_ops_of_the_reference():
+    """B = 0: the reference's torch ops return an empty (0, N, D) tensor (and empty input gradients); the C ABI rejects empty shapes,
+    so the core wrappers answer before calling it."""
+    from mop_amd.nn import EdgewiseMSA, BaselineMSA, MultiHopMSA, CrossViewMixerMSA
+    mods = [EdgewiseMSA(128, 4, n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2),
+            EdgewiseMSA(128, 4, n_views=3, share_qkv=True, gate_mode="dense", use_k3=True),
+            BaselineMSA(128, 4), MultiHopMSA(128, 4), CrossViewMixerMSA(128, 4)]
+    for m in mods:
+        m = m.cuda().to(torch.bfloat16)
+        x = torch.zeros(0, 17, 128, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+        y = m(x)
+        assert tuple(y.shape) == (0, 17, 128), type(m).__name__
+        y.sum().backward()
+        assert tuple(x.grad.shape) == (0, 17, 128)
