@@ -380,12 +380,38 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
                 g["W3"], g["b3"], g["lens_w"], None, None, None, None, None, None, None)
 
 
+def _half_via_fp32(fn):
+    """float16 callers (`module.half()`, fp16 autocast): the kernels take float32 / bfloat16 only, so half tensors go through the
+    float32 arithmetic (a superset of fp16) and the result is cast back; autograd carries the casts."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        def is_h(a):
+            return isinstance(a, torch.Tensor) and a.dtype == torch.float16
+        flat = list(args) + list(kw.values())
+        if not any(is_h(a) or (isinstance(a, (tuple, list)) and any(is_h(b) for b in a)) for a in flat):
+            return fn(*args, **kw)
+        def up(a):
+            if is_h(a):
+                return a.float()
+            if isinstance(a, (tuple, list)):
+                return type(a)(up(b) for b in a)
+            return a
+        out = fn(*[up(a) for a in args], **{k: up(v) for k, v in kw.items()})
+        def down(o):
+            return o.half() if isinstance(o, torch.Tensor) and o.dtype == torch.float32 and o.dim() == 3 else o
+        return tuple(down(o) for o in out) if isinstance(out, tuple) else down(out)
+    return wrapped
+
+
 def _empty_batch(t: torch.Tensor, *shape) -> torch.Tensor:
     """B = 0: the reference's torch ops return an empty result; the C ABI rejects empty shapes.  An empty tensor that still hangs
     on `t` in the autograd graph (its backward hands `t` an empty gradient)."""
     return t.new_zeros(shape) + t.sum() * 0
 
 
+@_half_via_fp32
 def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float, n_views: int, variant: EdgewiseVariant,
                           W3=None, b3=None, lens_w=None, precision: Optional[int] = None, dropout_p: float = 0.0,
                           seed: Optional[int] = None, attn_mask=None):
@@ -404,6 +430,7 @@ def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float
                                     e if lens_w is None else lens_w, beta_not, n_views, prec, variant, wants_grad, drop, attn_mask)
 
 
+@_half_via_fp32
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,
                           n_views: int, precision: Optional[int] = None, path: Optional[int] = None,
                           dropout_p: float = 0.0, seed: Optional[int] = None):
@@ -543,6 +570,7 @@ def dropout_keep_mask(seed: int, p: float, B: int, H: int, N: int) -> torch.Tens
     return torch.from_numpy(keep.reshape(B, H, N, N)) if p > 0 else torch.ones(B, H, N, N, dtype=torch.bool)
 
 
+@_half_via_fp32
 def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
     """q,k,v: (B,N,H,dk) views. Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive.  dropout_p > 0: the probabilities
     are multiplied by keep / (1 - p) inside the fused kernels (mask = `dropout_keep_mask(seed, ...)`, seed drawn when None)."""
@@ -617,6 +645,7 @@ class _CrossViewFn(torch.autograd.Function):
         return (*outs, dmix.sum((0, 1)).view(2, 2), None, None, None, None)
 
 
+@_half_via_fp32
 def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, anchor_mode="argmax_row_sum", fixed_k_star=0,
                    attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
     """q*,k*,v1: (B,N,H,dk) views; mix (2,2).  prior_weight = 0 disables the per-key prior.  Returns (B,N,H*dk)."""
@@ -711,6 +740,7 @@ class _DualPathFn(torch.autograd.Function):
         return (*gs, dlg.sum().reshape(()), None, None, None, None, None, None, None, None)
 
 
+@_half_via_fp32
 def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_chain, beta_not, hops,
                   attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
     if q1.shape[0] == 0:
@@ -805,6 +835,7 @@ class _QuartetFn(torch.autograd.Function):
         return (gs[0], gs[1], gs[2], None, None, None, None, None, None, None, None, None, None, None)
 
 
+@_half_via_fp32
 def quartet_core(q, k, v, q2, k2, mixture, quartet_scale, add_mask, eps, use_quartet, need_weights=False,
                  dropout_p: float = 0.0, seed: Optional[int] = None):
     if q.shape[0] == 0:                   # q: (B,T,H,dk)

@@ -588,3 +588,27 @@ def test_empty_batch_returns_an_empty_result_like_the_torch_ops_of_the_reference
         assert tuple(y.shape) == (0, 17, 128), type(m).__name__
         y.sum().backward()
         assert tuple(x.grad.shape) == (0, 17, 128)
+
+
+def test_float16_modules_run_through_the_float32_arithmetic():
+    """`module.half()`: the kernels take float32 / bfloat16; half tensors are computed in float32 (a superset) and cast back, so the
+    result equals the float32 module's up to the fp16 rounding of parameters, activations and the output."""
+    import mop_amd
+    from mop_amd.nn import EdgewiseMSA, BaselineMSA, MultiHopMSA
+    mop_amd.set_precision("auto")
+    for ctor in (lambda: EdgewiseMSA(128, 4, n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2, gate_init="mix5"),
+                 lambda: EdgewiseMSA(128, 4, n_views=3, share_qkv=True, gate_mode="dense"),
+                 lambda: BaselineMSA(128, 4), lambda: MultiHopMSA(128, 4)):
+        torch.manual_seed(11)
+        m32 = ctor().cuda()
+        x = torch.randn(2, 33, 128, device="cuda")
+        y32 = m32(x)
+        m16 = ctor().cuda()
+        m16.load_state_dict(m32.state_dict())
+        m16 = m16.half()
+        xh = x.half().requires_grad_(True)
+        y16 = m16(xh)
+        assert y16.dtype == torch.float16
+        y16.float().square().sum().backward()
+        assert torch.isfinite(xh.grad).all() and xh.grad.dtype == torch.float16
+        assert float((y16.detach().float() - y32.detach()).abs().max()) <= 2e-2 * max(1.0, float(y32.detach().abs().max())), type(m32).__name__
