@@ -47,36 +47,47 @@ __device__ __forceinline__ void fa_stage(unsigned short *rows, unsigned short *c
         }
     }
 }
-// the same staging split in two so the global loads of tile t+1 fly while tile t is computed:
-// fa_fetch (global -> registers), fa_put (registers -> LDS images)
-template <int DK> struct FaTile { bf16x8 v[FA_KT * (DK / 8) / (FA_NW * 64)]; };
+// The same staging split in two so the global loads of tile t+1 fly while tile t is computed: fa_fetch (global -> registers),
+// fa_put (registers -> LDS images).  The registers hold MFMA A fragments: wave w owns the 32-token half (w & 1) and the 32-feature
+// tile (w >> 1) of the 64-token tile, lane (r, h) the two 16-byte chunks [32 dt + 16 kk + 8 h, +8) of token row 32 s2 + r.  The
+// row image takes them as they are; the transposed image is the fragment pair times the identity on the matrix core (exact): the
+// product comes back with lane = feature, registers = tokens in accumulator order -- which IS the k-permuted column order the
+// consumers read -- so it is two 16-byte LDS stores per lane, not sixteen 2-byte scatter stores with 8-way bank conflicts.
+template <int DK> struct FaTile { bf16x8 v[2]; };
 template <int DK, typename IOT>
 __device__ __forceinline__ void fa_fetch(FaTile<DK> &f, const IOT *base, int64_t sn, int t0, int N, float scale, int tid) {
-    constexpr int CH = DK / 8, NC = FA_KT * CH / (FA_NW * 64);
+    const int w = tid >> 6, r = tid & 31, h = (tid >> 5) & 1, s2 = w & 1, dt = w >> 1, row = t0 + 32 * s2 + r;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const int c = tid + k * FA_NW * 64, j = c / CH, dc = c % CH;
+    for (int kk = 0; kk < 2; ++kk) {
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (t0 + j < N) v = load8_bf16<IOT>(base + (int64_t)(t0 + j) * sn + dc * 8);
+        if (dt < DK / 32 && row < N) v = load8_bf16<IOT>(base + (int64_t)row * sn + 32 * dt + 16 * kk + 8 * h);
         if (scale != 1.f) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((unsigned short)v[e]) * scale);
         }
-        f.v[k] = v;
+        f.v[kk] = v;
     }
 }
 template <int DK, bool ROWS, bool COLS>
 __device__ __forceinline__ void fa_put(unsigned short *rows, unsigned short *cols, const FaTile<DK> &f, int tid) {
-    constexpr int CH = DK / 8, NC = FA_KT * CH / (FA_NW * 64), LDK = DK + 8;
+    constexpr int LDK = DK + 8;
+    const int w = tid >> 6, r = tid & 31, h = (tid >> 5) & 1, s2 = w & 1, dt = w >> 1;
+    if (dt >= DK / 32) return;            // dk = 32: two waves cover the tile
+    if (ROWS) {
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        const int c = tid + k * FA_NW * 64, j = c / CH, dc = c % CH;
-        if (ROWS) *(bf16x8 *)&rows[j * LDK + dc * 8] = f.v[k];
-        if (COLS) {
-            const int col = (j & ~15) + kperm16(j & 15);
+        for (int kk = 0; kk < 2; ++kk) *(bf16x8 *)&rows[(32 * s2 + r) * LDK + 32 * dt + 16 * kk + 8 * h] = f.v[kk];
+    }
+    if (COLS) {
+        bf16x8 id0, id1;                  // B fragments of the 32 x 32 identity, k-steps 0 and 1: element e of lane (n, h) is [16 kk + 8 h + e == n]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) cols[(dc * 8 + e) * FA_LDT + col] = (unsigned short)f.v[k][e];
-        }
+        for (int e = 0; e < 8; ++e) { id0[e] = (short)(r == 8 * h + e ? 0x3f80 : 0); id1[e] = (short)(r == 16 + 8 * h + e ? 0x3f80 : 0); }
+        f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[0], id0, fa_zero(), 0, 0, 0);
+        tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.v[1], id1, tr, 0, 0, 0);
+        bf16x8 lo, hi;
+        fa_pack(lo, hi, tr);              // exact: every entry is one bf16 value times 1.0
+        unsigned short *dst = &cols[(32 * dt + r) * FA_LDT + 32 * s2 + 8 * h];
+        *(bf16x8 *)dst = lo;
+        *(bf16x8 *)(dst + 16) = hi;
     }
 }
 // 32x32 tile: sum_s A[(row0 + r)][16 s + 8 h ..] x B[s]   (A from a row-major LDS image with stride DK+8)
