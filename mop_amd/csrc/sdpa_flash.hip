@@ -183,7 +183,7 @@ __global__ void sdpa_flash_delta_kernel(MopkSdpaArgs a, float *delta) {
 
 // dQ: one workgroup per 128 queries, loop over key tiles
 template <int DK, typename IOT, bool CAUSAL, bool DUAL, bool MB>
-__global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs a, const float *lse, const float *delta, FaDual u) {
+__global__ void __launch_bounds__(FA_NW * 64, (DUAL || MB) ? 2 : 3) sdpa_flash_dq_kernel(MopkSdpaArgs a, const float *lse, const float *delta, FaDual u) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vs[FA_KT * LDK], Kt[DK * FA_LDT];
     __shared__ __attribute__((aligned(16))) unsigned short K2s[DUAL ? FA_KT * LDK : 8], K2t[DUAL ? DK * FA_LDT : 8];
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dq_kernel(MopkSdpaArgs 
 
 // dK, dV: one workgroup per 128 keys (a lane owns a key), loop over query tiles
 template <int DK, typename IOT, bool CAUSAL, bool DUAL, bool MB>
-__global__ void __launch_bounds__(FA_NW * 64) sdpa_flash_dkv_kernel(MopkSdpaArgs a, const float *lse, const float *delta, FaDual u) {
+__global__ void __launch_bounds__(FA_NW * 64, DUAL ? 1 : 2) sdpa_flash_dkv_kernel(MopkSdpaArgs a, const float *lse, const float *delta, FaDual u) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Qs[FA_KT * LDK], Gs[FA_KT * LDK], Qt[DK * FA_LDT], Gt[DK * FA_LDT];
     __shared__ __attribute__((aligned(16))) unsigned short Q2s[DUAL ? FA_KT * LDK : 8], Q2t[DUAL ? DK * FA_LDT : 8];
