@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_stats_kernel(MopkQuartetArgs a,
 
 // ------------------------------------------------------------------ pass 2: mixed logits, causal online softmax, A v
 template <int DK, typename IOT, bool DUAL, bool AM>
-__global__ void __launch_bounds__(FA_NW * 64) qt_fwd_kernel(MopkQuartetArgs a, const float *stats, float *lse) {
+__global__ void __launch_bounds__(FA_NW * 64, 2) qt_fwd_kernel(MopkQuartetArgs a, const float *stats, float *lse) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vt[DK * FA_LDT], K2s[DUAL ? FA_KT * LDK : 8];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -222,7 +222,7 @@ __global__ void qt_delta_kernel(MopkQuartetArgs a, float *delta) {          // d
 
 // row sums of the z-norm backward over the causal region + per-block partials of the two scalar gradients
 template <int DK, typename IOT, bool DUAL, bool AM>
-__global__ void __launch_bounds__(FA_NW * 64) qt_rowsum_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
+__global__ void __launch_bounds__(FA_NW * 64, 2) qt_rowsum_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
                                                                float *rows, float *spart) {
     constexpr int LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vs[FA_KT * LDK], K2s[DUAL ? FA_KT * LDK : 8];
@@ -314,7 +314,7 @@ __device__ __forceinline__ float qt_dscore(float dz, float s, const QtNorm &n) {
 
 // dQ (and dQ2): per query block over ALL key tiles (the z-norm correction is dense)
 template <int DK, typename IOT, bool DUAL, bool AM>
-__global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
+__global__ void __launch_bounds__(FA_NW * 64, 2) qt_dq_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
                                                            const float *rows) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Ks[FA_KT * LDK], Vs[FA_KT * LDK], Kt[DK * FA_LDT];
@@ -390,7 +390,7 @@ __global__ void __launch_bounds__(FA_NW * 64) qt_dq_kernel(MopkQuartetArgs a, co
 
 // dK, dK2, dV: per key block (lane = key) over ALL query tiles
 template <int DK, typename IOT, bool DUAL, bool AM>
-__global__ void __launch_bounds__(FA_NW * 64) qt_dkv_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
+__global__ void __launch_bounds__(FA_NW * 64, 2) qt_dkv_kernel(MopkQuartetArgs a, const float *stats, const float *lse, const float *delta,
                                                             const float *rows) {
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Qs[FA_KT * LDK], Gs[FA_KT * LDK], Qt[DK * FA_LDT], Gt[DK * FA_LDT];
