@@ -298,22 +298,26 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 1 : 2) sdpa_flash_dkv_kerne
     fa_fetch<DK, IOT>(fq, qp, a.q.sn, qt0 * FA_KT, N, c, tid);
     fa_fetch<DK, IOT>(fg, gp, a.dy.sn, qt0 * FA_KT, N, 1.f, tid);
     if (DUAL) fa_fetch<DK, IOT>(fq2, q2p, u.q2.sn, qt0 * FA_KT, N, c, tid);
+    // the tile's row statistics travel with the prefetch too (loaded between the barriers they cost one exposed round trip per tile)
+    float nl = 0.f, nd = 0.f;
+    auto fetch_stats = [&](int i0) {
+        const bool ok = tid < FA_KT && i0 + tid < N;
+        nl = ok ? lse[(int64_t)bh * N + i0 + tid] : 0.f;
+        nd = ok ? delta[(int64_t)bh * N + i0 + tid] : 0.f;
+    };
+    fetch_stats(qt0 * FA_KT);
     for (int qt = qt0; qt < nqt; ++qt) {
         const int i0 = qt * FA_KT;
         __syncthreads();
         fa_put<DK, true, true>(Qs, Qt, fq, tid);
         fa_put<DK, true, true>(Gs, Gt, fg, tid);
         if (DUAL) fa_put<DK, true, true>(Q2s, Q2t, fq2, tid);
+        if (tid < FA_KT) { Ls[tid] = nl; Ds[tid] = nd; Hs[tid] = fa_drop_row(drop, bh, i0 + tid); }
         if (qt + 1 < nqt) {
             fa_fetch<DK, IOT>(fq, qp, a.q.sn, i0 + FA_KT, N, c, tid);
             fa_fetch<DK, IOT>(fg, gp, a.dy.sn, i0 + FA_KT, N, 1.f, tid);
             if (DUAL) fa_fetch<DK, IOT>(fq2, q2p, u.q2.sn, i0 + FA_KT, N, c, tid);
-        }
-        if (tid < FA_KT) {
-            const bool ok = i0 + tid < N;
-            Ls[tid] = ok ? lse[(int64_t)bh * N + i0 + tid] : 0.f;
-            Ds[tid] = ok ? delta[(int64_t)bh * N + i0 + tid] : 0.f;
-            Hs[tid] = fa_drop_row(drop, bh, i0 + tid);
+            fetch_stats(i0 + FA_KT);
         }
         __syncthreads();
 #pragma unroll
