@@ -25,7 +25,7 @@ namespace mopk {
 // HEAD: 0 = low-rank gate head, 1 = dense gate head without the 3x3 convolution (launch A: per-edge MLP backward; launch B: log C<-
 //       gradient slab in the <- chain's seed; launch C: the S_v^T feature gradients added transposed)
 template <int NT, int DK, typename IOT, int PH, int HEAD = 0>
-__global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W, FusedDenseW dw) {
+__global__ void __launch_bounds__(NT * 64, NT <= 4 ? 2 : 1) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W, FusedDenseW dw) {
     using Cfg = BwdCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = DK + 8, KS = DK / 16, DT = Cfg::DT, DP = Cfg::DP;
     constexpr int NTH = NT * 64;
@@ -1458,9 +1458,16 @@ __global__ void __launch_bounds__(NT * 64) ew_fused_bwd_kernel(MopkEdgewiseArgs 
 #define MOPK_CAT_(a, b, c, d) a##b##c##d
 #define MOPK_CAT(a, b, c, d) MOPK_CAT_(a, b, c, d)
 #if MOPK_INST_NT != 0
-static int bwd_grid(const MopkEdgewiseArgs *a, int items_per_bh) {       // one persistent workgroup per CU
-    const int n = a->B * a->H * items_per_bh;
-    return n < 256 ? n : 256;
+// persistent workgroups: as many per CU as its registers (two waves per SIMD at 256 VGPRs) and LDS hold -- one for N > 128, two for
+// 64 < N <= 96 (the reference's CIFAR sequence length, N = 65), four / eight below
+static int bwd_grid(const MopkEdgewiseArgs *a, int items_per_bh) {
+    constexpr int NT = MOPK_INST_NT;
+    const int lds = BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::lds_bytes(a->V);
+    int per_cu = NT <= 4 ? 8 / NT : 1;
+    if (lds * per_cu > 160 * 1024) per_cu = 160 * 1024 / lds;
+    if (per_cu < 1) per_cu = 1;
+    const int n = a->B * a->H * items_per_bh, cap = 256 * per_cu;
+    return n < cap ? n : cap;
 }
 static size_t a256h(size_t x) { return (x + 255) & ~(size_t)255; }
 // workspace = [per-workgroup scratch x grid | per-(b,h) hand-off x B*H | (save_for_backward == 0 only) full `saved` record + y scratch
@@ -1571,20 +1578,21 @@ int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 #define MOPK_DECL(NT_, DK_) int ew_fused_bwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st); \
                             size_t ew_fused_bwd_ws_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a);
 MOPK_DECL(1, 16) MOPK_DECL(1, 32) MOPK_DECL(1, 64) MOPK_DECL(2, 16) MOPK_DECL(2, 32) MOPK_DECL(2, 64)
-MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
+MOPK_DECL(3, 16) MOPK_DECL(3, 32) MOPK_DECL(3, 64) MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
 #undef MOPK_DECL
-static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
+static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 96 ? 3 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
 #define MOPK_BWD_DISPATCH(PFX, ...)                                                   \
     switch (pick_nt_b(a->N)) {                                                       \
         case 1: switch (a->dk) { case 16: return PFX##nt1_dk16(__VA_ARGS__); case 32: return PFX##nt1_dk32(__VA_ARGS__); default: return PFX##nt1_dk64(__VA_ARGS__); } \
         case 2: switch (a->dk) { case 16: return PFX##nt2_dk16(__VA_ARGS__); case 32: return PFX##nt2_dk32(__VA_ARGS__); default: return PFX##nt2_dk64(__VA_ARGS__); } \
+        case 3: switch (a->dk) { case 16: return PFX##nt3_dk16(__VA_ARGS__); case 32: return PFX##nt3_dk32(__VA_ARGS__); default: return PFX##nt3_dk64(__VA_ARGS__); } \
         case 4: switch (a->dk) { case 16: return PFX##nt4_dk16(__VA_ARGS__); case 32: return PFX##nt4_dk32(__VA_ARGS__); default: return PFX##nt4_dk64(__VA_ARGS__); } \
         default: switch (a->dk) { case 16: return PFX##nt7_dk16(__VA_ARGS__); case 32: return PFX##nt7_dk32(__VA_ARGS__); default: return PFX##nt7_dk64(__VA_ARGS__); } \
     }
 template <int NT, int DK> static int lds_bwd(int V) { return BwdCfg<NT, DK>::lds_bytes(V); }
 int ew_fused_bwd_lds_bytes(int nt, int dk, int V) {
 #define MOPK_L(NT_) (dk == 16 ? lds_bwd<NT_, 16>(V) : dk == 32 ? lds_bwd<NT_, 32>(V) : lds_bwd<NT_, 64>(V))
-    switch (nt) { case 1: return MOPK_L(1); case 2: return MOPK_L(2); case 4: return MOPK_L(4); case 7: return MOPK_L(7); default: return 1 << 30; }
+    switch (nt) { case 1: return MOPK_L(1); case 2: return MOPK_L(2); case 3: return MOPK_L(3); case 4: return MOPK_L(4); case 7: return MOPK_L(7); default: return 1 << 30; }
 #undef MOPK_L
 }
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {

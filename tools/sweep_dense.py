@@ -9,7 +9,7 @@ from mop_amd.nn import EdgewiseMSA
 torch.manual_seed(0)
 mop_amd.set_precision("bf16")
 bad = 0
-cases = [(B, N, H, dk, V, dt) for (N, B) in ((5, 3), (32, 2), (33, 1), (64, 2), (100, 1), (129, 1), (197, 2), (224, 1))
+cases = [(B, N, H, dk, V, dt) for (N, B) in ((5, 3), (32, 2), (33, 1), (64, 2), (65, 2), (96, 1), (100, 1), (129, 1), (197, 2), (224, 1))
          for (H, dk) in ((2, 16), (1, 32), (2, 64)) for V in (2, 3, 5, 6) for dt in (torch.bfloat16, torch.float32)]
 for i, (B, N, H, dk, V, dt) in enumerate(cases):
     D = H * dk
