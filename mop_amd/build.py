@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libmopk.so")
 PLAIN = ["api.hip", "edgewise_generic.hip", "attn_generic.hip", "sdpa_flash.hip", "quartet_flash.hip", "layernorm.hip"]
 FUSED = ["edgewise_fused.hip", "edgewise_fused_bwd.hip"]
 FUSED_INST_ONLY = []      # files compiled per (NT, DK) only (entry points called from the files above)
-NTS, DKS = (1, 2, 3, 4, 7), (16, 32, 64)      # NT = 3: N <= 96 (the reference's CIFAR sequence length, N = 65)
+NTS, DKS = (1, 2, 3, 4, 5, 6, 7), (16, 32, 64)      # NT = 3: N <= 96 (the reference's CIFAR sequence length, N = 65)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 if os.environ.get("MOPK_EXTRA_FLAGS"):  # compiler experiments, e.g. MOPK_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
     FLAGS += os.environ["MOPK_EXTRA_FLAGS"].split()

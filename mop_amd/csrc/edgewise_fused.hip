@@ -855,15 +855,15 @@ int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
 #define MOPK_DECL(NT_, DK_) int ew_fused_fwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st); \
                             size_t ew_fused_saved_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a);
 MOPK_DECL(1, 16) MOPK_DECL(1, 32) MOPK_DECL(1, 64) MOPK_DECL(2, 16) MOPK_DECL(2, 32) MOPK_DECL(2, 64)
-MOPK_DECL(3, 16) MOPK_DECL(3, 32) MOPK_DECL(3, 64) MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
+MOPK_DECL(3, 16) MOPK_DECL(3, 32) MOPK_DECL(3, 64) MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(5, 16) MOPK_DECL(5, 32) MOPK_DECL(5, 64) MOPK_DECL(6, 16) MOPK_DECL(6, 32) MOPK_DECL(6, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
 #undef MOPK_DECL
-static int pick_nt(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 96 ? 3 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
+static int pick_nt(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 96 ? 3 : N <= 128 ? 4 : N <= 160 ? 5 : N <= 192 ? 6 : N <= 224 ? 7 : 0; }
 int ew_fused_bwd_lds_bytes(int nt, int dk, int V);
 template <int NT, int DK> static int lds_fwd(int V) { return FusedCfg<NT, DK>::lds_bytes(V); }
 static int ew_fused_lds_bytes(int nt, int dk, int V) {
     int f = 1 << 30;
 #define MOPK_L(NT_) (dk == 16 ? lds_fwd<NT_, 16>(V) : dk == 32 ? lds_fwd<NT_, 32>(V) : lds_fwd<NT_, 64>(V))
-    switch (nt) { case 1: f = MOPK_L(1); break; case 2: f = MOPK_L(2); break; case 3: f = MOPK_L(3); break; case 4: f = MOPK_L(4); break; case 7: f = MOPK_L(7); break; default: break; }
+    switch (nt) { case 1: f = MOPK_L(1); break; case 2: f = MOPK_L(2); break; case 3: f = MOPK_L(3); break; case 4: f = MOPK_L(4); break; case 5: f = MOPK_L(5); break; case 6: f = MOPK_L(6); break; case 7: f = MOPK_L(7); break; default: break; }
 #undef MOPK_L
     const int bw = ew_fused_bwd_lds_bytes(nt, dk, V);
     return f > bw ? f : bw;
@@ -894,7 +894,7 @@ int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
 
 size_t ew_fused_saved_bytes(const MopkEdgewiseArgs *a) {
 #define MOPK_DKS(NT_) switch (a->dk) { case 16: return ew_fused_saved_nt##NT_##_dk16(a); case 32: return ew_fused_saved_nt##NT_##_dk32(a); default: return ew_fused_saved_nt##NT_##_dk64(a); }
-    switch (pick_nt(a->N)) { case 1: MOPK_DKS(1) case 2: MOPK_DKS(2) case 3: MOPK_DKS(3) case 4: MOPK_DKS(4) case 7: MOPK_DKS(7) default: return 0; }
+    switch (pick_nt(a->N)) { case 1: MOPK_DKS(1) case 2: MOPK_DKS(2) case 3: MOPK_DKS(3) case 4: MOPK_DKS(4) case 5: MOPK_DKS(5) case 6: MOPK_DKS(6) case 7: MOPK_DKS(7) default: return 0; }
 #undef MOPK_DKS
 }
 int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
@@ -910,6 +910,8 @@ int ew_fused_fwd(const MopkEdgewiseArgs *a, hipStream_t st) {
         case 2: MOPK_DK(2)
         case 3: MOPK_DK(3)
         case 4: MOPK_DK(4)
+        case 5: MOPK_DK(5)
+        case 6: MOPK_DK(6)
         default: MOPK_DK(7)
     }
 #undef MOPK_DK

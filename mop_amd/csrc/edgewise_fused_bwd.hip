@@ -1578,21 +1578,23 @@ int ew_fused_fwd_supported(const MopkEdgewiseArgs *a);
 #define MOPK_DECL(NT_, DK_) int ew_fused_bwd_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a, hipStream_t st); \
                             size_t ew_fused_bwd_ws_nt##NT_##_dk##DK_(const MopkEdgewiseArgs *a);
 MOPK_DECL(1, 16) MOPK_DECL(1, 32) MOPK_DECL(1, 64) MOPK_DECL(2, 16) MOPK_DECL(2, 32) MOPK_DECL(2, 64)
-MOPK_DECL(3, 16) MOPK_DECL(3, 32) MOPK_DECL(3, 64) MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
+MOPK_DECL(3, 16) MOPK_DECL(3, 32) MOPK_DECL(3, 64) MOPK_DECL(4, 16) MOPK_DECL(4, 32) MOPK_DECL(4, 64) MOPK_DECL(5, 16) MOPK_DECL(5, 32) MOPK_DECL(5, 64) MOPK_DECL(6, 16) MOPK_DECL(6, 32) MOPK_DECL(6, 64) MOPK_DECL(7, 16) MOPK_DECL(7, 32) MOPK_DECL(7, 64)
 #undef MOPK_DECL
-static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 96 ? 3 : N <= 128 ? 4 : N <= 224 ? 7 : 0; }
+static int pick_nt_b(int N) { return N <= 32 ? 1 : N <= 64 ? 2 : N <= 96 ? 3 : N <= 128 ? 4 : N <= 160 ? 5 : N <= 192 ? 6 : N <= 224 ? 7 : 0; }
 #define MOPK_BWD_DISPATCH(PFX, ...)                                                   \
     switch (pick_nt_b(a->N)) {                                                       \
         case 1: switch (a->dk) { case 16: return PFX##nt1_dk16(__VA_ARGS__); case 32: return PFX##nt1_dk32(__VA_ARGS__); default: return PFX##nt1_dk64(__VA_ARGS__); } \
         case 2: switch (a->dk) { case 16: return PFX##nt2_dk16(__VA_ARGS__); case 32: return PFX##nt2_dk32(__VA_ARGS__); default: return PFX##nt2_dk64(__VA_ARGS__); } \
         case 3: switch (a->dk) { case 16: return PFX##nt3_dk16(__VA_ARGS__); case 32: return PFX##nt3_dk32(__VA_ARGS__); default: return PFX##nt3_dk64(__VA_ARGS__); } \
         case 4: switch (a->dk) { case 16: return PFX##nt4_dk16(__VA_ARGS__); case 32: return PFX##nt4_dk32(__VA_ARGS__); default: return PFX##nt4_dk64(__VA_ARGS__); } \
+        case 5: switch (a->dk) { case 16: return PFX##nt5_dk16(__VA_ARGS__); case 32: return PFX##nt5_dk32(__VA_ARGS__); default: return PFX##nt5_dk64(__VA_ARGS__); } \
+        case 6: switch (a->dk) { case 16: return PFX##nt6_dk16(__VA_ARGS__); case 32: return PFX##nt6_dk32(__VA_ARGS__); default: return PFX##nt6_dk64(__VA_ARGS__); } \
         default: switch (a->dk) { case 16: return PFX##nt7_dk16(__VA_ARGS__); case 32: return PFX##nt7_dk32(__VA_ARGS__); default: return PFX##nt7_dk64(__VA_ARGS__); } \
     }
 template <int NT, int DK> static int lds_bwd(int V) { return BwdCfg<NT, DK>::lds_bytes(V); }
 int ew_fused_bwd_lds_bytes(int nt, int dk, int V) {
 #define MOPK_L(NT_) (dk == 16 ? lds_bwd<NT_, 16>(V) : dk == 32 ? lds_bwd<NT_, 32>(V) : lds_bwd<NT_, 64>(V))
-    switch (nt) { case 1: return MOPK_L(1); case 2: return MOPK_L(2); case 3: return MOPK_L(3); case 4: return MOPK_L(4); case 7: return MOPK_L(7); default: return 1 << 30; }
+    switch (nt) { case 1: return MOPK_L(1); case 2: return MOPK_L(2); case 3: return MOPK_L(3); case 4: return MOPK_L(4); case 5: return MOPK_L(5); case 6: return MOPK_L(6); case 7: return MOPK_L(7); default: return 1 << 30; }
 #undef MOPK_L
 }
 int ew_fused_bwd_supported(const MopkEdgewiseArgs *a) {

@@ -16,7 +16,7 @@ def timed(fn, n=20):
     return (time.time() - t) / n * 1e3
 
 
-for N, B in ((65, 256), (65, 1024), (128, 256), (197, 256)):
+for N, B in ((65, 256), (65, 1024), (128, 256), (145, 256), (170, 256), (197, 256)):
     torch.manual_seed(0)
     m = EdgewiseMSA(384, 6, n_views=5, share_qkv=True, gate_mode="lowrank", gate_rank=4).cuda().to(torch.bfloat16)
     x = torch.randn(B, N, 384, device="cuda", dtype=torch.bfloat16, requires_grad=True)
