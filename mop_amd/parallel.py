@@ -37,19 +37,16 @@ class FlatGradBucket:
         world = dist.get_world_size(self.group)
         if world == 1:
             return
-        for p, (s, e) in zip(self.params, self.offsets):
-            g = p.grad
-            if g is None:
-                self.flat[s:e].zero_()
-            else:
-                self.flat[s:e].copy_(g.reshape(-1))
+        views = [self.flat[s:e].view_as(p) for p, (s, e) in zip(self.params, self.offsets)]
+        for p, v in zip(self.params, views):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in self.params]
+        torch._foreach_copy_(views, grads)          # pack: one multi-tensor launch instead of one copy per parameter
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         if average:
             self.flat.div_(world)
-        for p, (s, e) in zip(self.params, self.offsets):
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(self.flat[s:e].view_as(p))
+        torch._foreach_copy_(grads, views)          # unpack (casts back to the parameter dtype)
 
 
 def shard_batch(n_items: int, rank: int, world: int):
