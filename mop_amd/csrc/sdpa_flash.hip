@@ -165,20 +165,36 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 2 : 3) sdpa_flash_fwd_kerne
 }
 
 // ------------------------------------------------------------------ backward
-// delta_i = sum_d dy[i,d] y[i,d]  ( = sum_j P_ij dP_ij ); one wave per row
+// delta_i = sum_d dy[i,d] y[i,d]  ( = sum_j P_ij dP_ij ); dk / 8 lanes per row, 16-byte loads (one wave per row moved 2 bytes per lane)
+__device__ __forceinline__ void fa_ld8(const unsigned short *p, float (&v)[8]) {
+    const bf16x8 x = *(const bf16x8 *)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f((unsigned short)x[e]);
+}
+__device__ __forceinline__ void fa_ld8(const float *p, float (&v)[8]) {
+    const float4 a = *(const float4 *)p, b = *(const float4 *)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
 template <typename IOT>
 __global__ void sdpa_flash_delta_kernel(MopkSdpaArgs a, float *delta) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (int64_t)a.B * a.H * a.N) return;
-    const int lane = threadIdx.x & 63, i = row % a.N;
-    const int64_t bh = row / a.N;
-    const int b = bh / a.H, hh = bh % a.H;
-    const IOT *yp = (const IOT *)a.y.ptr + b * a.y.sb + hh * a.y.sh + (int64_t)i * a.y.sn;
-    const IOT *gp = (const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)i * a.dy.sn;
+    const int cpr = a.dk >> 3;                                  // 16-byte chunks (= lanes) per row: 4 or 8
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / cpr;
+    const int ch = threadIdx.x % cpr;
     float s = 0.f;
-    for (int d = lane; d < a.dk; d += 64) s = fmaf(ld_as_f32(yp + d), ld_as_f32(gp + d), s);
-    s = wave_sum(s);
-    if (lane == 0) delta[row] = s;
+    if (row < (int64_t)a.B * a.H * a.N) {
+        const int i = row % a.N;
+        const int64_t bh = row / a.N;
+        const int b = bh / a.H, hh = bh % a.H;
+        float y[8], g[8];
+        fa_ld8((const IOT *)a.y.ptr + b * a.y.sb + hh * a.y.sh + (int64_t)i * a.y.sn + 8 * ch, y);
+        fa_ld8((const IOT *)a.dy.ptr + b * a.dy.sb + hh * a.dy.sh + (int64_t)i * a.dy.sn + 8 * ch, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(y[e], g[e], s);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (cpr == 8) s += __shfl_xor(s, 4, 64);
+    if (ch == 0 && row < (int64_t)a.B * a.H * a.N) delta[row] = s;
 }
 
 // dQ: one workgroup per 128 queries, loop over key tiles
@@ -398,8 +414,8 @@ int sdpa_flash_bwd(const MopkSdpaArgs *a, hipStream_t st) {
     if (!sdpa_flash_supported(a, true)) return MOPK_ERR_UNSUPPORTED;
     const int64_t rows = (int64_t)a->B * a->H * a->N;
     float *delta = (float *)a->workspace;
-    if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
-    else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
+    if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows * (a->dk / 8) + 255) / 256), dim3(256), 0, st, *a, delta);
+    else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows * (a->dk / 8) + 255) / 256), dim3(256), 0, st, *a, delta);
     MOPK_CHECK_LAUNCH();
     const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
     FA_DISPATCH(sdpa_flash_dq_kernel, false, grid, *a, (const float *)a->saved, (const float *)delta, FaDual{});
@@ -448,26 +464,52 @@ template <typename T> __device__ __forceinline__ T *dp_at(const MopkView4 &v, in
     const int d = idx % dk; const int n = (idx / dk) % N; const int64_t bh = idx / ((int64_t)dk * N);
     return (T *)v.ptr + (bh / H) * v.sb + (bh % H) * v.sh + (int64_t)n * v.sn + d;
 }
+// the three element-wise passes of the dual path work on 8 consecutive features per thread (16-byte accesses; dk is 32 or 64 and the
+// views are 16-byte aligned on this path): idx8 indexes the (b,h,n,d/8) chunks
+__device__ __forceinline__ void fa_st8(unsigned short *p, const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (short)f2bf(v[e]);
+    *(bf16x8 *)p = x;
+}
+__device__ __forceinline__ void fa_st8(float *p, const float (&v)[8]) {
+    *(float4 *)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4 *)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
 template <typename T>
 __global__ void dp_combine_kernel(MopkView4 y, MopkView4 o1, MopkView4 yc, const float *logit, int H, int N, int dk, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (idx >= total) return;
     const float w = 1.f / (1.f + __expf(-*logit));
-    st_from_f32(dp_at<T>(y, idx, H, N, dk), ld_as_f32(dp_at<T>(o1, idx, H, N, dk)) + w * ld_as_f32(dp_at<T>(yc, idx, H, N, dk)));   // :229
+    float a[8], c[8];
+    fa_ld8(dp_at<T>(o1, idx, H, N, dk), a);
+    fa_ld8(dp_at<T>(yc, idx, H, N, dk), c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = a[e] + w * c[e];                                                                    // :229
+    fa_st8(dp_at<T>(y, idx, H, N, dk), a);
 }
 template <typename T>
 __global__ void dp_scale_kernel(MopkView4 out, MopkView4 in, const float *logit, int H, int N, int dk, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (idx >= total) return;
     const float w = 1.f / (1.f + __expf(-*logit));
-    st_from_f32(dp_at<T>(out, idx, H, N, dk), w * ld_as_f32(dp_at<T>(in, idx, H, N, dk)));
+    float a[8];
+    fa_ld8(dp_at<T>(in, idx, H, N, dk), a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= w;
+    fa_st8(dp_at<T>(out, idx, H, N, dk), a);
 }
 template <typename T>
 __global__ void dp_add_kernel(MopkView4 out, MopkView4 in, int H, int N, int dk, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (idx >= total) return;
     T *o = dp_at<T>(out, idx, H, N, dk);
-    st_from_f32(o, ld_as_f32(o) + ld_as_f32(dp_at<T>(in, idx, H, N, dk)));
+    float a[8], c[8];
+    fa_ld8(o, a);
+    fa_ld8(dp_at<T>(in, idx, H, N, dk), c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += c[e];
+    fa_st8(o, a);
 }
 template <typename T>
 __global__ void dp_dlogit_kernel(MopkView4 dy, MopkView4 yc, const float *logit, float *out, int H, int N, int dk) {
@@ -480,9 +522,9 @@ __global__ void dp_dlogit_kernel(MopkView4 dy, MopkView4 yc, const float *logit,
     if (threadIdx.x == 0) { const float w = 1.f / (1.f + __expf(-*logit)); out[bh] = red[0] * w * (1.f - w); }
 }
 #define DP_ELEM(KERNEL, ...)                                                                                        \
-    do { const int64_t tot_ = (int64_t)a->B * a->H * a->N * a->dk;                                                 \
-         if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((KERNEL<unsigned short>), dim3((tot_ + 255) / 256), dim3(256), 0, st, __VA_ARGS__, a->H, a->N, a->dk, tot_); \
-         else hipLaunchKernelGGL((KERNEL<float>), dim3((tot_ + 255) / 256), dim3(256), 0, st, __VA_ARGS__, a->H, a->N, a->dk, tot_); } while (0)
+    do { const int64_t tot_ = (int64_t)a->B * a->H * a->N * a->dk, thr_ = tot_ / 8;                                \
+         if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((KERNEL<unsigned short>), dim3((thr_ + 255) / 256), dim3(256), 0, st, __VA_ARGS__, a->H, a->N, a->dk, tot_); \
+         else hipLaunchKernelGGL((KERNEL<float>), dim3((thr_ + 255) / 256), dim3(256), 0, st, __VA_ARGS__, a->H, a->N, a->dk, tot_); } while (0)
 }  // namespace
 
 int dp_flash_supported(const MopkDualPathArgs *a, bool bwd) {
@@ -515,8 +557,8 @@ static int dp_plain_bwd(const MopkDualPathArgs *d, const MopkView4 &q, const Mop
     s.q = q; s.k = k; s.v = v; s.y = y; s.dy = dy; s.dq = dq; s.dk_ = dk; s.dv = dv;
     const MopkSdpaArgs *a = &s;
     const int64_t rows = (int64_t)a->B * a->H * a->N;
-    if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
-    else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, st, *a, delta);
+    if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows * (a->dk / 8) + 255) / 256), dim3(256), 0, st, *a, delta);
+    else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows * (a->dk / 8) + 255) / 256), dim3(256), 0, st, *a, delta);
     const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
     FA_DISPATCH(sdpa_flash_dq_kernel, false, grid, *a, lse, (const float *)delta, FaDual{});
     FA_DISPATCH(sdpa_flash_dkv_kernel, false, grid, *a, lse, (const float *)delta, FaDual{});
@@ -571,8 +613,8 @@ int dp_flash_bwd(const MopkDualPathArgs *a, hipStream_t st) {
         s.dropout_p = a->dropout_p; s.dropout_seed = a->dropout_seed;
         FaDual u{a->q2, a->k2, a->dq2, a->dk2, a->g_and - a->beta_not * a->g_not, a->g_or};
         const int64_t rows = (int64_t)a->B * a->H * a->N;
-        if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows + 3) / 4), dim3(256), 0, st, s, W.delta);
-        else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows + 3) / 4), dim3(256), 0, st, s, W.delta);
+        if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((sdpa_flash_delta_kernel<unsigned short>), dim3((rows * (s.dk / 8) + 255) / 256), dim3(256), 0, st, s, W.delta);
+        else hipLaunchKernelGGL((sdpa_flash_delta_kernel<float>), dim3((rows * (s.dk / 8) + 255) / 256), dim3(256), 0, st, s, W.delta);
         const dim3 grid(((a->N + FA_QB - 1) / FA_QB) * a->B * a->H);
         const MopkSdpaArgs *keep = &s;
         { const MopkSdpaArgs *a = keep; FA_DISPATCH(sdpa_flash_dq_kernel, true, grid, *a, (const float *)L.lse_m, (const float *)W.delta, u);
