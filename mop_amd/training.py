@@ -50,10 +50,12 @@ class DataParallelStep:
     """loss = loss_fn(model(x), y) on the local shard; gradients averaged over ranks with one flat all-reduce."""
 
     def __init__(self, model: nn.Module, optimizer: optim.Optimizer, loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
-                 scheduler: Optional[optim.lr_scheduler.LRScheduler] = None):
+                 scheduler: Optional[optim.lr_scheduler.LRScheduler] = None, params=None):
+        """`model` may be any callable (e.g. the graphed callable of `torch.cuda.make_graphed_callables`); then pass `params`."""
         self.model, self.opt, self.loss_fn, self.sched = model, optimizer, loss_fn, scheduler
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.bucket = FlatGradBucket([p for p in model.parameters() if p.requires_grad]) if self.world > 1 else None
+        params = [p for p in model.parameters() if p.requires_grad] if params is None else list(params)
+        self.bucket = FlatGradBucket(params) if self.world > 1 else None
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         self.opt.zero_grad(set_to_none=True)

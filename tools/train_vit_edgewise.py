@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--weight-decay", type=float, default=5e-2)
     ap.add_argument("--warmup-frac", type=float, default=0.1)
     ap.add_argument("--ckpt", type=str, default="")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the model's forward + backward into HIP graphs (torch.cuda.make_graphed_callables) and replay them; "
+                         "the optimizer step stays eager")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -44,10 +47,12 @@ def main():
     model = ViTEdgewise(dim=args.dim, depth=args.depth, heads=args.heads, n_classes=100, n_views=args.views, share_qkv=True,
                         gate_mode="lowrank", gate_rank=4, gate_init="mix5", drop_path=0.0).cuda().to(torch.bfloat16)
     opt, sched = make_optimizer_and_schedule(model, args.lr, args.weight_decay, args.steps, args.warmup_frac)
-    step = DataParallelStep(model, opt, lambda out, tgt: F.cross_entropy(out.float(), tgt), sched)
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)            # each rank draws its own shard
     x = torch.randn(args.batch, 3, 32, 32, device="cuda", generator=g).to(torch.bfloat16)
     y = torch.randint(0, 100, (args.batch,), device="cuda", generator=g)
+    net = torch.cuda.make_graphed_callables(model, (x,)) if args.graph else model   # same parameters; kernels are stream-ordered, no host syncs
+    step = DataParallelStep(net, opt, lambda out, tgt: F.cross_entropy(out.float(), tgt), sched,
+                            params=[p for p in model.parameters() if p.requires_grad])
     for _ in range(3):
         step(x, y)
     torch.cuda.synchronize()
