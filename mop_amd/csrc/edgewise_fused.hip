@@ -40,7 +40,7 @@ namespace mopk {
 //       the mix tile loop: the score tiles of both orientations are recomputed per register quarter (40 MFMAs -- the matrix pipe is
 //       idle here), the 16 hidden units of four edges per lane live in registers, C<- comes back from this wave's own export.
 template <int NT, int DK, typename IOT, bool SAVE, int HEAD = 0>
-__global__ void __launch_bounds__(NT * 64, NT <= 4 ? 2 : 1) ew_fused_fwd_kernel(MopkEdgewiseArgs a, FusedDenseW dw) {
+__global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(MopkEdgewiseArgs a, FusedDenseW dw) {
     using Cfg = FusedCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = Cfg::LDK, KS = Cfg::KS, DT = Cfg::DT, DP = Cfg::DP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

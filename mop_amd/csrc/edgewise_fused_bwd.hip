@@ -25,7 +25,7 @@ namespace mopk {
 // HEAD: 0 = low-rank gate head, 1 = dense gate head without the 3x3 convolution (launch A: per-edge MLP backward; launch B: log C<-
 //       gradient slab in the <- chain's seed; launch C: the S_v^T feature gradients added transposed)
 template <int NT, int DK, typename IOT, int PH, int HEAD = 0>
-__global__ void __launch_bounds__(NT * 64, NT <= 4 ? 2 : 1) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W, FusedDenseW dw) {
+__global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(MopkEdgewiseArgs a, BwdWs W, FusedDenseW dw) {
     using Cfg = BwdCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = DK + 8, KS = DK / 16, DT = Cfg::DT, DP = Cfg::DP;
     constexpr int NTH = NT * 64;
@@ -1463,7 +1463,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 4 ? 2 : 1) ew_fused_bwd_kernel(
 static int bwd_grid(const MopkEdgewiseArgs *a, int items_per_bh) {
     constexpr int NT = MOPK_INST_NT;
     const int lds = BwdCfg<MOPK_INST_NT, MOPK_INST_DK>::lds_bytes(a->V);
-    int per_cu = NT <= 4 ? 8 / NT : 1;
+    int per_cu = NT <= 3 ? 8 / NT : 1;            // matches the __launch_bounds__ occupancy hint of the kernels
     if (lds * per_cu > 160 * 1024) per_cu = 160 * 1024 / lds;
     if (per_cu < 1) per_cu = 1;
     const int n = a->B * a->H * items_per_bh, cap = 256 * per_cu;
