@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--workload", default="layer", choices=["layer", "vit"],
                     help="layer: one EdgewiseMSA layer fwd+bwd (BASELINE.json configs[1], the metric's workload at every N); "
                          "vit: ViT-MoP 5.4 M training step with AdamW (configs[2], 256 images per GPU)")
+    ap.add_argument("--graph", action="store_true",
+                    help="vit workload only: replay the model's forward + backward as HIP graphs (torch.cuda.make_graphed_callables); "
+                         "that step is launch-bound in eager mode (~270 launches for 3.3 ms of kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="rehearse the multi-process protocol on CPU (gloo): rendezvous, one flat gradient all-reduce per step, "
@@ -208,10 +211,12 @@ def main():
         torch.manual_seed(0)                           # identical initial weights on every rank
         model = ViT_MoP(dim=VIT["dim"], depth=VIT["depth"], heads=VIT["heads"], n_classes=VIT["n_classes"], drop_path=0.0).cuda().to(dtype)
         opt, sched = make_optimizer_and_schedule(model, 3e-3, 5e-2, steps=max(args.steps + args.warmup + 1, 2))
-        dp = DataParallelStep(model, opt, lambda out, tgt: F.cross_entropy(out.float(), tgt), sched)   # flat all-reduce inside
         params = [p for p in model.parameters()]
         xi = torch.randn(B, 3, VIT["img"], VIT["img"], device="cuda", generator=g).to(dtype)
         yi = torch.randint(0, VIT["n_classes"], (B,), device="cuda", generator=g)
+        net = torch.cuda.make_graphed_callables(model, (xi,)) if args.graph else model
+        dp = DataParallelStep(net, opt, lambda out, tgt: F.cross_entropy(out.float(), tgt), sched,
+                              params=[p for p in params if p.requires_grad])                              # flat all-reduce inside
 
         def step():
             dp(xi, yi)
@@ -261,7 +266,8 @@ def main():
             out["config"] = {"workload": "ViT_MoP(dim 384, depth 3, heads 6, 100 classes) training step on 32x32 images: fwd + bwd + "
                                          "one flat gradient all-reduce + AdamW (BASELINE.json configs[2])", "per_gpu_batch": B,
                              "params": sum(p.numel() for p in params), "parallelism": par,
-                             "grad_allreduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0}
+                             "grad_allreduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0,
+                             "hip_graph": bool(args.graph)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "layer":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
