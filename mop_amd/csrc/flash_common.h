@@ -26,27 +26,6 @@ __device__ __forceinline__ void fa_frags(bf16x8 (&f)[DK / 16], const IOT *row, b
         f[s] = v;
     }
 }
-// stage a tile of TK tokens: row-major image rows[tok][DK+8] and/or transposed image cols[d][perm(tok)]
-template <int DK, typename IOT, bool ROWS, bool COLS>
-__device__ __forceinline__ void fa_stage(unsigned short *rows, unsigned short *cols, const IOT *base, int64_t sn, int t0, int N,
-                                         float scale, int tid) {
-    constexpr int CH = DK / 8, LDK = DK + 8;
-    for (int c = tid; c < FA_KT * CH; c += FA_NW * 64) {
-        const int j = c / CH, dc = c % CH;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (t0 + j < N) v = load8_bf16<IOT>(base + (int64_t)(t0 + j) * sn + dc * 8);
-        if (scale != 1.f) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((unsigned short)v[e]) * scale);
-        }
-        if (ROWS) *(bf16x8 *)&rows[j * LDK + dc * 8] = v;
-        if (COLS) {
-            const int col = (j & ~15) + kperm16(j & 15);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cols[(dc * 8 + e) * FA_LDT + col] = (unsigned short)v[e];
-        }
-    }
-}
 // The same staging split in two so the global loads of tile t+1 fly while tile t is computed: fa_fetch (global -> registers),
 // fa_put (registers -> LDS images).  The registers hold MFMA A fragments: wave w owns the 32-token half (w & 1) and the 32-feature
 // tile (w >> 1) of the 64-token tile, lane (r, h) the two 16-byte chunks [32 dt + 16 kk + 8 h, +8) of token row 32 s2 + r.  The
@@ -89,6 +68,14 @@ __device__ __forceinline__ void fa_put(unsigned short *rows, unsigned short *col
         *(bf16x8 *)dst = lo;
         *(bf16x8 *)(dst + 16) = hi;
     }
+}
+// stage a tile of 64 tokens in one go (no prefetch): row-major image rows[tok][DK+8] and/or transposed image cols[d][perm(tok)]
+template <int DK, typename IOT, bool ROWS, bool COLS>
+__device__ __forceinline__ void fa_stage(unsigned short *rows, unsigned short *cols, const IOT *base, int64_t sn, int t0, int N,
+                                         float scale, int tid) {
+    FaTile<DK> f;
+    fa_fetch<DK, IOT>(f, base, sn, t0, N, scale, tid);
+    fa_put<DK, ROWS, COLS>(rows, cols, f, tid);
 }
 // 32x32 tile: sum_s A[(row0 + r)][16 s + 8 h ..] x B[s]   (A from a row-major LDS image with stride DK+8)
 template <int DK>
