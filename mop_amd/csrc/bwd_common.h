@@ -1,6 +1,6 @@
 // Shared definitions of the fused Edgewise backward launches (edgewise_fused_bwd.hip): workspace carve-up, slab ids of the hand-off region, packed-tile helpers.
 #pragma once
-#include "/root/repo/mop_amd/csrc/fused_common.h"
+#include "fused_common.h"
 
 namespace mopk {
 
