@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmopk.so")
+LIB_PATH = os.environ.get("MOPK_LIB") or os.path.join(HERE, "libmopk.so")   # MOPK_LIB: dev builds (tools/build_variant.py)
 
 MOPK_F32, MOPK_BF16 = 0, 1
 PREC_FP32, PREC_BF16 = 0, 1

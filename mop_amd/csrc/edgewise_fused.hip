@@ -25,6 +25,9 @@
 #ifdef MOPK_WHATIF_NOBAR       // timing experiment only (results are wrong)
 #define __syncthreads() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #endif
+#ifndef MOPK_PF
+#define MOPK_PF 4
+#endif
 namespace mopk {
 
 // workgroup barrier for LDS hand-offs: waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
@@ -44,8 +47,10 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     using Cfg = FusedCfg<NT, DK>;
     constexpr int NP = Cfg::NP, LDA = Cfg::LDA, LDK = Cfg::LDK, KS = Cfg::KS, DT = Cfg::DT, DP = Cfg::DP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short *AT = (unsigned short *)smem;                   // [NP][LDA]   A_m^T, k-permuted columns
-    unsigned short *VT0 = AT;                                      // [DP][LDA]   (aliases AT after the chains)
+    unsigned short *AT = (unsigned short *)smem;                   // R region
+    unsigned short *ring = AT;                                     // [RING][32][LDA]  parts of A_m^T (rows = keys, k-permuted query columns)
+    unsigned short *Qsm = AT + Cfg::RING * Cfg::PART;              // [NP][LDK]   q rows (chains only)
+    unsigned short *VT0 = AT;                                      // [DP][LDA]   (aliases the ring / q rows after the chains)
     unsigned short *VTL = AT + DP * LDA;                           // [DP][LDA]
     unsigned short *bT = AT + 2 * DP * LDA;                        // [4][NP][BTS]
     unsigned short *Ksm = (unsigned short *)(smem + Cfg::R_BYTES); // [NP][LDK]
@@ -54,7 +59,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     float *rCr = vsL + DK, *rCl = rCr + NP, *cCr = rCl + NP, *cCl = cCr + NP;
     float *colpart = cCl + NP;                                     // [NT][NP]
     float *rS = colpart + NT * NP, *cS = rS + a.V * NP;            // [V][NP]
-    float *cst = rS;                                               // [V][NP] softmax constants c_v[i] = log2 sum_j 2^(S'_v[i,j]); aliases rS (dead until the gate phase)
+    float *cst = rS;                                               // [V][NP] NEGATED softmax constants -c_v[i], c = log2 sum_j 2^(S'_v[i,j]); aliases rS (dead until the gate phase)
     float *wsig = cS + a.V * NP;
 
     const int tid = threadIdx.x, w = tid >> 6;
@@ -73,6 +78,13 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
 #else
 #define FSTAMP() do { } while (0)
 #endif
+#ifdef MOPK_STAMPS3
+    // timeline of ONE part (<- chain, step 2, tile 3) for wave 0 (slots 0-15) and its SIMD partner wave 4 (slots 16-31)
+#define FSTAMP3(i_) do { if (!forward && m == 2 && to == 3) { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && (tid == 0 || tid == 256)) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((unsigned long long *)cCr)[(tid ? 16 : 0) + (i_)] = t_; } __builtin_amdgcn_sched_barrier(0); \
+        if ((i_) == 11 && blockIdx.x == 0 && tid < 32) ((unsigned long long *)a.workspace)[tid] = ((unsigned long long *)cCr)[tid]; } } while (0)
+#else
+#define FSTAMP3(i_) do { } while (0)
+#endif
 #ifdef MOPK_STAMPS2
 #define FSTAMP2(c_) do { if (c_) FSTAMP(); } while (0)
 #else
@@ -83,12 +95,14 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     // ---------------- P0: stage K, q fragments, scales ----------------
     {
         const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh;
+        const IOT *qp0 = (const IOT *)a.q.ptr + b * a.q.sb + hh * a.q.sh;
         constexpr int CH = DK / 8;
         for (int c = tid; c < NP * CH; c += NT * 64) {
             const int j = c / CH, dc = c % CH;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (j < N) v = load8_bf16<IOT>(kp + (int64_t)j * a.k.sn + dc * 8);
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}, u = v;
+            if (j < N) { v = load8_bf16<IOT>(kp + (int64_t)j * a.k.sn + dc * 8); u = load8_bf16<IOT>(qp0 + (int64_t)j * a.q.sn + dc * 8); }
             *(bf16x8 *)&Ksm[j * LDK + dc * 8] = v;
+            *(bf16x8 *)&Qsm[j * LDK + dc * 8] = u;
         }
         for (int c = tid; c < V * DK; c += NT * 64) { const float t = a.sqk[((c / DK) * H + hh) * DK + (c % DK)]; sqk[c] = t; sqk2[c] = t * 1.4426950408889634f; }
         for (int c = tid; c < DK; c += NT * 64) { vs0[c] = a.vs0[hh * DK + c]; vsL[c] = a.vsL[hh * DK + c]; }
@@ -226,93 +240,234 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
         if ((r & 1) == 0) colpart[w * NP + 32 * t + tile_row(r >> 1, h)] = c[0];
     };
     // chain product (transposed, row-block local):  X <- A_{o[V-1]}^T .. A_{o[1]}^T A_{o[0]}^T[:, I]
-    // the last step hands every fp32 output tile to `epi(to, acc)`
+    // the last step hands every fp32 output tile to `epi(to, acc)`.
+    //
+    // Part pipeline.  The A operand of step m is the image A_m^T (rows = keys, k-permuted query columns).  It is never resident as a
+    // whole: it streams through a ring of two 32-key PARTS.  Per part every wave (1) builds its 32 x 32 piece of the NEXT part --
+    // keys of that part x its own queries -- and (2) multiplies the CURRENT part into its row block (one output tile, 2 NT MFMAs),
+    // then one barrier.  The piece is computed with the operands of the score MFMA swapped (A = this wave's scaled q fragments,
+    // B = the part's K rows): the tile comes out with lane = key, registers = queries, which is the image's row order -- two 16-byte
+    // LDS stores, no transpose -- and the softmax constant of a query, now a per-REGISTER value, enters as the initial accumulator
+    // (-c from LDS), so the tile needs 16 exp2 and no subtraction.  A piece depends on q, k and the row constants only, never on the
+    // chain state, so the stream runs across the step boundaries: 4 NT parts per chain, the only serial dependency is each wave's
+    // own slab.  SIMD partners (waves w, w + 4) run build / multiply in opposite order, so one's exp2 / pack work sits beside the
+    // other's MFMAs.
     const bool klast = N > NP - 16;        // N <= NP - 16: the last 16-wide k-step of every contraction over keys is all padding
-    auto run_chain = [&](bool forward, auto &&epi) {
-        bf16x8 Xp[NT][2];
-        bf16x8 idl, idh;
-        identity_frags(idl, idh, r, h);
-        // the <- chain (run first) computes every view's softmax constant once and parks it in LDS for the -> chain
-        auto view_const = [&](const bf16x8 (&qe)[KS], int v) -> float {
-            if (forward) return cst[v * NP + qi];
-            const float c = row_const(qe);
-            if (h == 0) cst[v * NP + qi] = c;
-            return c;
-        };
+    auto load_qe2 = [&](bf16x8 (&qe)[KS], int v) {      // Qe_v fragments x log2(e) of this lane's query, q from the LDS rows
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 qv = *(const bf16x8 *)&Qsm[qi * LDK + 16 * s + 8 * h];
+            const float4 s0 = *(const float4 *)&sqk2[v * DK + 16 * s + 8 * h], s1 = *(const float4 *)&sqk2[v * DK + 16 * s + 8 * h + 4];
+            const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qe[s][j] = (short)f2bf(bf2f((unsigned short)qv[j]) * sc[j]);
+        }
+    };
+    auto build_piece = [&](const bf16x8 (&qe)[KS], int v, int to, int slot) {
+        f32x16 acc;
+        const float *nc = cst + v * NP + 32 * w + 4 * h;            // -c of queries 32w + 8 q4 + 4h + {0..3} = rows of registers 4 q4 ..
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 c4 = *(const float4 *)&nc[8 * q4];
+            acc[4 * q4] = c4.x; acc[4 * q4 + 1] = c4.y; acc[4 * q4 + 2] = c4.z; acc[4 * q4 + 3] = c4.w;
+        }
+        bf16x8 kf[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) kf[s] = *(const bf16x8 *)&(Ksm + r * LDK + 8 * h)[(32 * to) * LDK + 16 * s];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qe[s], kf[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = __builtin_amdgcn_exp2f(acc[g]);
+        if (32 * to + 32 > N) {
+            const bool dead = 32 * to + r >= N;                     // this lane's key is padding: its image row is zero
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[g] = dead ? 0.f : acc[g];
+        }
+        bf16x8 lo, hi;
+        pack_tile(lo, hi, acc);
+        unsigned short *dst = ring + slot * Cfg::PART + r * LDA + 32 * w + 8 * h;
+        *(bf16x8 *)dst = lo;
+        *(bf16x8 *)(dst + 16) = hi;
+    };
+    auto run_chain = [&](bool forward, bf16x8 (&Xp)[NT][2], auto &&epi) {      // Xp: the final product, packed, on return
+        bf16x8 Xn[NT][2];
+        bf16x8 qe[KS];
         {
             const int v = forward ? 0 : V - 1;
-            bf16x8 qe[KS];
-            make_qe2(qe, v);
-            const float c = view_const(qe, v);
+            load_qe2(qe, v);
+            const float c = -cst[v * NP + qi];
 #pragma unroll
             for (int t = 0; t < NT; ++t) { const f32x16 A = a_tile(qe, t, c); pack_tile(Xp[t][0], Xp[t][1], A); }
         }
+        LDS_BARRIER();                       // the ring is free (previous chain / phase)
+        bf16x8 idl, idh;                     // identity fragments of the export transposes: kept live (regenerating them costs 48 VALU
+        identity_frags(idl, idh, r, h);      // instructions per part, and the vector ALU, not the matrix pipe, is what a part waits for)
+        load_qe2(qe, forward ? 1 : V - 2);
+        build_piece(qe, forward ? 1 : V - 2, 0, 0);
+        LDS_BARRIER();
+        int cur = 0;                         // ring slot of the current part
         for (int m = 1; m < V; ++m) {
-            // this step's query fragments are requested BEFORE the export stores below: vmcnt retires in order (stores included), so
-            // a load issued behind the 14 export stores would wait for all of them (~16 k cycles per step at the HBM write rate)
             const int v = forward ? m : V - 1 - m;
-            bf16x8 qe[KS];
-            make_qe2(qe, v);
-            if (SAVE) {
-                // export the prefix product for the backward's dA GEMMs in "row slab" order: wave w' of the backward reads, per
-                // lane (key a = 32w' + r'), the fragments {T[i, a] : i} -> [wave w'][chunk q][lane], 16 B each.  That is the
-                // TRANSPOSE of the tiles this wave holds (lane = query, registers = keys); it is taken on the matrix core:
-                // D = X . I (two MFMAs per tile with identity B fragments) comes back with lane = key, registers = queries,
-                // and its packed halves are exactly chunks q = 2w, 2w+1 of wave t's slab.  No LDS round trip, no barrier.
-                // (non-temporal stores: the record is not read again by this kernel; streaming it past L2 took 8 % off the forward)
-                typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-                u4 *out = (u4 *)(svb + (forward ? SL.oT : SL.oU) + (size_t)(m - 1) * NP * LDA * 2) + lane;
+            const bool last = m == V - 1;
+            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+            u4 *out = (u4 *)(svb + (forward ? SL.oT : SL.oU) + (size_t)(m - 1) * NP * LDA * 2) + lane;
+            static_for<0, NT>([&](auto tc) {
+                // One part = one hand-ordered instruction stream: the three independent jobs of a part -- the next piece (score MFMAs, exp2,
+                // pack, LDS stores), this part's product (2 NT MFMAs on LDS fragments) and the export of one prefix tile (two transposing
+                // MFMAs, pack, stores) -- are interleaved so that the VALU work sits in the shadow of the product's MFMAs.
+                // One barrier per part: the piece of part P + 1 is written while part P is read (two ring slots).
+                constexpr int to = decltype(tc)::value;
+                constexpr bool wrap = to + 1 == NT;
+                constexpr int tb = wrap ? 0 : to + 1;                     // key tile of the next part
+                constexpr int NK = 2 * NT, PF = NK < MOPK_PF ? NK : MOPK_PF;
+                FSTAMP2(!forward && m == 2);
+                FSTAMP3(0);
+                const int nxt = cur ^ 1;
+                // the next part: tile to + 1 of this step, or tile 0 of the next step's view (the chain's very last part rebuilds a piece
+                // nobody reads: one dummy piece per chain keeps the stream branch-free)
+                const int vb = (wrap && !last) ? (forward ? m + 1 : V - 2 - m) : v;
+                if (wrap && !last) load_qe2(qe, vb);
+                // (B) next piece: -c of this wave's queries (a per-REGISTER constant in this orientation) as the initial accumulator, K rows
+                f32x16 bacc;
+                {
+                    const float *nc = cst + vb * NP + 32 * w + 4 * h;   // -c of queries 32w + 8 q4 + 4h + {0..3} = rows of registers 4 q4 ..
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    f32x16 tr = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xp[t][0], idl, tr, 0, 0, 0);
-                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xp[t][1], idh, tr, 0, 0, 0);
-                    bf16x8 lo, hi;
-                    pack_tile(lo, hi, tr);    // exact: every entry is one bf16 value times 1.0
-                    __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &out[((size_t)t * 2 * NT + 2 * w) * 64]);
-                    __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &out[((size_t)t * 2 * NT + 2 * w + 1) * 64]);
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float4 c4 = *(const float4 *)&nc[8 * q4];
+                        bacc[4 * q4] = c4.x; bacc[4 * q4 + 1] = c4.y; bacc[4 * q4 + 2] = c4.z; bacc[4 * q4 + 3] = c4.w;
+                    }
                 }
-            }
-            {
-                FSTAMP2(forward && m == 1);
-                const float c = view_const(qe, v);
-                FSTAMP2(forward && m == 1);
-                LDS_BARRIER();              // previous step's readers of AT are done
-                FSTAMP2(forward && m == 1);
-#pragma unroll 2
-                for (int t = 0; t < NT; ++t) {
-                    const f32x16 A = a_tile(qe, t, c);
-                    bf16x8 lo, hi;
-                    pack_tile(lo, hi, A);
-                    // AT[key][perm(query)]: the tile is transposed on the matrix core (lane = key, registers = this wave's 32 queries)
-                    // and leaves as two 16-byte LDS stores -- chunks 4w + h and 4w + 2 + h of image row 32t + r -- instead of sixteen
-                    // 2-byte ones
-                    f32x16 tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, idl, f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0);
-                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, idh, tr, 0, 0, 0);
-                    bf16x8 tl, th;
-                    pack_tile(tl, th, tr);
-                    unsigned short *dst = AT + (32 * t + r) * LDA + 32 * w + 8 * h;
-                    *(bf16x8 *)dst = tl;
-                    *(bf16x8 *)(dst + 16) = th;
+                bf16x8 kf[KS];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) kf[s] = *(const bf16x8 *)&(Ksm + r * LDK + 8 * h)[(32 * tb) * LDK + 16 * s];
+                FSTAMP3(1);
+                // (C) export of tile `to` of the prefix product for the backward's dA GEMMs in "row slab" order: wave w' of the backward
+                // reads, per lane (key a = 32w' + r'), the fragments {T[i, a] : i} -> [wave w'][chunk q][lane], 16 B each.  That is the
+                // TRANSPOSE of the tile this wave holds (lane = query, registers = keys), taken on the matrix core: D = X . I (two MFMAs
+                // with identity B fragments) comes back with lane = key, registers = queries, and its packed halves are exactly chunks
+                // q = 2w, 2w+1 of wave t's slab.  (non-temporal stores: the record is not read again by this kernel)
+                f32x16 tr = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef MOPK_WHATIF_NOEXPORT
+                constexpr bool EXPORT = false;
+#else
+                constexpr bool EXPORT = SAVE;
+#endif
+                if (EXPORT) {
+                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xp[to][0], idl, tr, 0, 0, 0);
+                    tr = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xp[to][1], idh, tr, 0, 0, 0);
                 }
-                FSTAMP2(forward && m == 1);
+                FSTAMP3(2);
+                // (D) scores of the next piece, operands swapped: lane = key, registers = queries
+#ifndef MOPK_WHATIF_NOBUILD
+#pragma unroll
+                for (int s = 0; s < KS; ++s) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qe[s], kf[s], bacc, 0, 0, 0);
+#endif
+                // (A) the first A fragments of this part
+                const unsigned abase = (unsigned)(uintptr_t)(ring + cur * Cfg::PART + r * LDA + 8 * h);
+                bf16x8 rg[PF];
+                static_for<0, PF>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    bf16x8 tmp;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(abase), "i"(32 * f));
+                    rg[f] = tmp;
+                });
+                FSTAMP3(3);
+                // (E) this part's product; k-step k carries filler(k)
+                bf16x8 plo, phi;
+                f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                static_for<0, NK>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    constexpr int pend = (NK - 1 - k) < (PF - 1) ? (NK - 1 - k) : (PF - 1);
+                    bf16x8 af = rg[k % PF];
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af) : "i"(pend));
+#ifndef MOPK_WHATIF_NOGEMM
+                    if (k < NK - 1 || klast) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[k >> 1][k & 1], acc, 0, 0, 0);
+#else
+                    if (k == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Xp[k >> 1][k & 1], acc, 0, 0, 0);
+                    asm volatile("" : "+v"(af));
+#endif
+                    if constexpr (k + PF < NK) {
+                        bf16x8 tmp;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(abase), "i"(32 * (k + PF)));
+                        rg[(k + PF) % PF] = tmp;
+                    }
+                    // fillers.  NK >= 8: export pack + stores at k = 0, 1; exp2 of the piece from k = 2 (its MFMAs are two latencies old);
+                    // pack at NK - 3, LDS stores at NK - 2.  Short chains (NT < 4) put everything behind the last MFMA.
+                    if constexpr (k == 1 || k == 4 || k == 7 || k == 10 || k == 12) FSTAMP3(4 + (k == 1 ? 0 : k == 4 ? 1 : k == 7 ? 2 : k == 10 ? 3 : 4));
+                    constexpr bool SHORT = NK < 8;
+                    if constexpr (!SHORT) {
+                        if constexpr (k == 0) {
+                            if (EXPORT) {
+                                bf16x8 lo, hi;
+                                pack_tile(lo, hi, tr);    // exact: every entry is one bf16 value times 1.0
+                                __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &out[((size_t)to * 2 * NT + 2 * w) * 64]);
+                                __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &out[((size_t)to * 2 * NT + 2 * w + 1) * 64]);
+                            }
+                        }
+                        constexpr int E0 = 2, ESTEPS = NK - 3 - E0;               // exp2 steps: k = E0 .. NK - 4
+                        if constexpr (k >= E0 && k < E0 + ESTEPS) {
+                            constexpr int g0 = 16 * (k - E0) / ESTEPS, g1 = 16 * (k - E0 + 1) / ESTEPS;
+#ifndef MOPK_WHATIF_NOBUILD
+#pragma unroll
+                            for (int g = g0; g < g1; ++g) bacc[g] = __builtin_amdgcn_exp2f(bacc[g]);
+#endif
+                        }
+                        if constexpr (k == NK - 3) {
+                            if (32 * tb + 32 > N) {
+                                const bool dead = 32 * tb + r >= N;             // this lane's key is padding: its image row is zero
+#pragma unroll
+                                for (int g = 0; g < 16; ++g) bacc[g] = dead ? 0.f : bacc[g];
+                            }
+                            pack_tile(plo, phi, bacc);
+                        }
+                        if constexpr (k == NK - 2) {
+                            unsigned short *dst = ring + nxt * Cfg::PART + r * LDA + 32 * w + 8 * h;
+                            *(bf16x8 *)dst = plo;
+                            *(bf16x8 *)(dst + 16) = phi;
+                        }
+                    }
+                });
+                if constexpr (NK < 8) {
+                    if (EXPORT) {
+                        bf16x8 lo, hi;
+                        pack_tile(lo, hi, tr);
+                        __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &out[((size_t)to * 2 * NT + 2 * w) * 64]);
+                        __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &out[((size_t)to * 2 * NT + 2 * w + 1) * 64]);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) bacc[g] = __builtin_amdgcn_exp2f(bacc[g]);
+                    if (32 * tb + 32 > N) {
+                        const bool dead = 32 * tb + r >= N;
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) bacc[g] = dead ? 0.f : bacc[g];
+                    }
+                    pack_tile(plo, phi, bacc);
+                    unsigned short *dst = ring + nxt * Cfg::PART + r * LDA + 32 * w + 8 * h;
+                    *(bf16x8 *)dst = plo;
+                    *(bf16x8 *)(dst + 16) = phi;
+                }
+                FSTAMP3(9);
+                pack_tile(Xn[to][0], Xn[to][1], acc);
+                if (last) epi(to, acc, Xn[to][0], Xn[to][1]);
+                FSTAMP3(10);
                 LDS_BARRIER();
-                FSTAMP2(forward && m == 1);
-            }
-            auto zero_init = [](int) { return f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
-            if (m < V - 1) {
-                bf16x8 Xn[NT][2];
-                gemm_stream_epi<NT>(AT + r * LDA + 8 * h, Xp, klast, zero_init,
-                                    [&](int to, const f32x16 &acc) { pack_tile(Xn[to][0], Xn[to][1], acc); });
+                FSTAMP3(11);
+                cur = nxt;
+            });
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
-                FSTAMP2(forward && m == 1);
-            } else {
-                gemm_stream_epi<NT>(AT + r * LDA + 8 * h, Xp, klast, zero_init, [&](int to, f32x16 acc) { epi(to, acc); });
-            }
+            for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }
         }
     };
 
+    FSTAMP();
+    REFRESH();
+    // ---------------- softmax constants of every view for this lane's query (wave-private: a wave only ever builds pieces of its own queries)
+    for (int v = 0; v < V; ++v) {
+        bf16x8 qe[KS];
+        load_qe2(qe, v);
+        const float c = row_const(qe);
+        if (h == 0) cst[v * NP + qi] = -c;
+    }
     FSTAMP();
     REFRESH();
     // ---------------- chain <- : only its log-means survive           :513-515, :521
@@ -320,8 +475,9 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
         float rs = 0.f;
         typedef __attribute__((ext_vector_type(4))) unsigned int u4;
         u4 *cbp = (u4 *)(svb + SL.oCB + (size_t)w * NT * 8 * 64 * 4) + lane;       // packed C<- slab of this wave
-        run_chain(false, [&](int to, f32x16 &acc) {
-            if (SAVE) { bf16x8 lo, hi; pack_tile(lo, hi, acc); __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &cbp[(2 * to) * 64]); __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &cbp[(2 * to + 1) * 64]); }
+        bf16x8 Xb[NT][2];
+        run_chain(false, Xb, [&](int to, f32x16 &acc, const bf16x8 &lo, const bf16x8 &hi) {
+            if (SAVE) { __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &cbp[(2 * to) * 64]); __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &cbp[(2 * to + 1) * 64]); }
             log_tile(acc, to, rs);
         });
         rs += __shfl_xor(rs, 32, 64);
@@ -337,7 +493,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     float *ych = (float *)(svb + SL.oYch);                         // saved: w * y_chain (N,dk) fp32
     {
         bf16x8 Xc[NT][2];
-        run_chain(true, [&](int to, f32x16 &acc) { pack_tile(Xc[to][0], Xc[to][1], acc); });
+        run_chain(true, Xc, [&](int, f32x16 &, const bf16x8 &, const bf16x8 &) {});
         if (SAVE) {
             typedef __attribute__((ext_vector_type(4))) unsigned int u4;
             u4 *cfp = (u4 *)(svb + SL.oCF + (size_t)w * NT * 8 * 64 * 4) + lane;
@@ -390,7 +546,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
                             if (SAVE) ((float *)(svb + SL.oMeans))[2 * NP + tid] = c; }
             if (SAVE) {   // softmax constants of every view (still in `cst`, about to be overwritten by rS) and the log-means
                 float *gc = (float *)(svb + SL.oCst), *gm = (float *)(svb + SL.oMeans);
-                for (int c = tid; c < V * NP; c += NT * 64) gc[c] = cst[c];
+                for (int c = tid; c < V * NP; c += NT * 64) gc[c] = -cst[c];
                 if (tid < NP) { gm[tid] = rCr[tid]; gm[NP + tid] = rCl[tid]; gm[3 * NP + tid] = cCl[tid]; }
                 LDS_BARRIER();          // cst fully copied before rS/cS overwrite it
             }

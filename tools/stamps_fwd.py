@@ -16,7 +16,7 @@ for _ in range(2):
         y = layer(x)
 torch.cuda.synchronize()
 st = struct.unpack("32Q", ops.LAST_PATH["_fwd_ws"][:256].cpu().numpy().tobytes())
-names = ["P0 stage + means", "chain <-", "chain -> (+exports, V^T, y_chain)", "gate vectors", "mix", "softmax + P V0"]
+names = ["P0 stage + means", "row constants", "chain <-", "chain -> (+exports, V^T, y_chain)", "gate vectors", "mix", "softmax + P V0"]
 vals = [s for s in st if s]
 tot = vals[-1] - vals[0]
 for i in range(len(vals) - 1):
