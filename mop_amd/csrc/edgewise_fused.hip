@@ -302,10 +302,18 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
         LDS_BARRIER();                       // the ring is free (previous chain / phase)
         bf16x8 idl, idh;                     // identity fragments of the export transposes: kept live (regenerating them costs 48 VALU
         identity_frags(idl, idh, r, h);      // instructions per part, and the vector ALU, not the matrix pipe, is what a part waits for)
+        // pieces are built LA parts ahead of the product and the workgroup meets at a barrier every LA parts (ring of 2 LA slots): the
+        // fixed cost of a rendezvous -- LDS round trips in front of the first MFMA, the last MFMA's latency, the barrier itself, about
+        // 900 cycles -- is paid per LA parts
+        constexpr int LA = Cfg::RING / 2;
         load_qe2(qe, forward ? 1 : V - 2);
-        build_piece(qe, forward ? 1 : V - 2, 0, 0);
+        static_for<0, LA>([&](auto pc) {
+            constexpr int p0 = decltype(pc)::value;
+            if constexpr (p0 < NT) build_piece(qe, forward ? 1 : V - 2, p0, p0);
+            else { if (V > 2) { load_qe2(qe, forward ? 2 : V - 3); build_piece(qe, forward ? 2 : V - 3, p0 - NT, p0); } }    // NT == 1, LA == 2: the second part is the next step's
+        });
         LDS_BARRIER();
-        int cur = 0;                         // ring slot of the current part
+        int cur = 0, P = 0;                  // ring slot of the current part, global part index
         for (int m = 1; m < V; ++m) {
             const int v = forward ? m : V - 1 - m;
             const bool last = m == V - 1;
@@ -317,16 +325,16 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
                 // MFMAs, pack, stores) -- are interleaved so that the VALU work sits in the shadow of the product's MFMAs.
                 // One barrier per part: the piece of part P + 1 is written while part P is read (two ring slots).
                 constexpr int to = decltype(tc)::value;
-                constexpr bool wrap = to + 1 == NT;
-                constexpr int tb = wrap ? 0 : to + 1;                     // key tile of the next part
+                constexpr bool wrap = to + LA >= NT;                     // the piece built here belongs to the next step
+                constexpr int tb = (to + LA) % NT;                       // its key tile
                 constexpr int NK = 2 * NT, PF = NK < MOPK_PF ? NK : MOPK_PF;
                 FSTAMP2(!forward && m == 2);
                 FSTAMP3(0);
-                const int nxt = cur ^ 1;
+                const int nxt = (cur + LA) & (Cfg::RING - 1);             // slot of the piece built here (part P + LA)
                 // the next part: tile to + 1 of this step, or tile 0 of the next step's view (the chain's very last part rebuilds a piece
                 // nobody reads: one dummy piece per chain keeps the stream branch-free)
                 const int vb = (wrap && !last) ? (forward ? m + 1 : V - 2 - m) : v;
-                if (wrap && !last) load_qe2(qe, vb);
+                if (to + LA == NT && !last) load_qe2(qe, vb);        // first piece of the next step's view (NT >= LA)
                 // (B) next piece: -c of this wave's queries (a per-REGISTER constant in this orientation) as the initial accumulator, K rows
                 f32x16 bacc;
                 {
@@ -450,9 +458,9 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
                 pack_tile(Xn[to][0], Xn[to][1], acc);
                 if (last) epi(to, acc, Xn[to][0], Xn[to][1]);
                 FSTAMP3(10);
-                LDS_BARRIER();
+                if (((P + 1) & (LA - 1)) == 0) LDS_BARRIER();
                 FSTAMP3(11);
-                cur = nxt;
+                cur = (cur + 1) & (Cfg::RING - 1); ++P;
             });
 #pragma unroll
             for (int t = 0; t < NT; ++t) { Xp[t][0] = Xn[t][0]; Xp[t][1] = Xn[t][1]; }

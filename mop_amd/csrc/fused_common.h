@@ -27,7 +27,7 @@ struct FusedCfg {
     static constexpr int NP = NT * 32, LDA = NP + 8, LDK = DK + 8, KS = DK / 16;
     static constexpr int DT = DK >= 32 ? DK / 32 : 1, DP = DT * 32;
     // R region: during the chains a ring of RING image parts (32 keys x LDA each) + the q rows [NP][LDK]; afterwards V0^T | VL^T | bT
-    static constexpr int RING = 2, PART = 32 * LDA;                 // ushorts per ring slot
+    static constexpr int RING = NT >= 2 ? 4 : 2, PART = 32 * LDA;    // ring slots (a power of two), ushorts per slot
     static constexpr int R_BYTES = imax(RING * PART * 2 + NP * LDK * 2, 2 * DP * LDA * 2 + 4 * NP * BTS * 2);
     static constexpr int K_BYTES = NP * LDK * 2;
     // fp32 scratch (floats): sqk sqk2 [8][DK] qbar kbar vs0 vsL [DK] | rCr rCl cCr cCl [NP] | colpart[NT][NP] | rS cS cst [V][NP] | wsig
