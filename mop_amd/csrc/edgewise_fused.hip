@@ -253,6 +253,9 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     // own slab.  SIMD partners (waves w, w + 4) run build / multiply in opposite order, so one's exp2 / pack work sits beside the
     // other's MFMAs.
     const bool klast = N > NP - 16;        // N <= NP - 16: the last 16-wide k-step of every contraction over keys is all padding
+    // ... and so is the last 16-B chunk of every packed slab of the record (keys / queries NP - 16 .. NP - 1): not stored (7 % of the export
+    // stream at N = 197); the backward does not load it either
+    const bool ctrim = SAVE && HEAD == 0 && !klast;
     auto load_qe2 = [&](bf16x8 (&qe)[KS], int v) {      // Qe_v fragments x log2(e) of this lane's query, q from the LDS rows
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -409,7 +412,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
                                 bf16x8 lo, hi;
                                 pack_tile(lo, hi, tr);    // exact: every entry is one bf16 value times 1.0
                                 __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &out[((size_t)to * 2 * NT + 2 * w) * 64]);
-                                __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &out[((size_t)to * 2 * NT + 2 * w + 1) * 64]);
+                                if (!(ctrim && w == NT - 1)) __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &out[((size_t)to * 2 * NT + 2 * w + 1) * 64]);
                             }
                         }
                         constexpr int E0 = 2, ESTEPS = NK - 3 - E0;               // exp2 steps: k = E0 .. NK - 4
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
                         bf16x8 lo, hi;
                         pack_tile(lo, hi, tr);
                         __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &out[((size_t)to * 2 * NT + 2 * w) * 64]);
-                        __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &out[((size_t)to * 2 * NT + 2 * w + 1) * 64]);
+                        if (!(ctrim && w == NT - 1)) __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &out[((size_t)to * 2 * NT + 2 * w + 1) * 64]);
                     }
 #pragma unroll
                     for (int g = 0; g < 16; ++g) bacc[g] = __builtin_amdgcn_exp2f(bacc[g]);
@@ -485,7 +488,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
         u4 *cbp = (u4 *)(svb + SL.oCB + (size_t)w * NT * 8 * 64 * 4) + lane;       // packed C<- slab of this wave
         bf16x8 Xb[NT][2];
         run_chain(false, Xb, [&](int to, f32x16 &acc, const bf16x8 &lo, const bf16x8 &hi) {
-            if (SAVE) { __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &cbp[(2 * to) * 64]); __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &cbp[(2 * to + 1) * 64]); }
+            if (SAVE) { __builtin_nontemporal_store(__builtin_bit_cast(u4, lo), &cbp[(2 * to) * 64]); if (!(ctrim && to == NT - 1)) __builtin_nontemporal_store(__builtin_bit_cast(u4, hi), &cbp[(2 * to + 1) * 64]); }
             log_tile(acc, to, rs);
         });
         rs += __shfl_xor(rs, 32, 64);
@@ -506,7 +509,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
             typedef __attribute__((ext_vector_type(4))) unsigned int u4;
             u4 *cfp = (u4 *)(svb + SL.oCF + (size_t)w * NT * 8 * 64 * 4) + lane;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { __builtin_nontemporal_store(__builtin_bit_cast(u4, Xc[t][0]), &cfp[(2 * t) * 64]); __builtin_nontemporal_store(__builtin_bit_cast(u4, Xc[t][1]), &cfp[(2 * t + 1) * 64]); }
+            for (int t = 0; t < NT; ++t) { __builtin_nontemporal_store(__builtin_bit_cast(u4, Xc[t][0]), &cfp[(2 * t) * 64]); if (!(ctrim && t == NT - 1)) __builtin_nontemporal_store(__builtin_bit_cast(u4, Xc[t][1]), &cfp[(2 * t + 1) * 64]); }
         }
         // log C-> from the bf16-rounded product (the same rounding the backward sees): means + packed fp16 copy
         float rs = 0.f;
@@ -724,7 +727,8 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
         if (SAVE) {                       // log C-> of this tile from the wave's own export: the same bf16 values, the same fp16 packing
             typedef __attribute__((ext_vector_type(4))) unsigned int u4;
             const u4 *cfp = (const u4 *)(svb + SL.oCF + (size_t)w * NT * 8 * 64 * 4) + lane;
-            const bf16x8 cl = __builtin_bit_cast(bf16x8, cfp[(2 * t) * 64]), ch = __builtin_bit_cast(bf16x8, cfp[(2 * t + 1) * 64]);
+            const bool tr1 = ctrim && t == NT - 1;              // trimmed chunk: the neighbour is re-read (its keys are padding, masked below)
+            const bf16x8 cl = __builtin_bit_cast(bf16x8, cfp[(2 * t) * 64]), ch = __builtin_bit_cast(bf16x8, cfp[(2 * t + (tr1 ? 0 : 1)) * 64]);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 cw[p] = pack_h2(__logf(bf2f((unsigned short)cl[2 * p]) + EPSC), __logf(bf2f((unsigned short)cl[2 * p + 1]) + EPSC));
@@ -766,7 +770,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
             f32x4 *lp = (f32x4 *)(svb + SL.oL + (size_t)w * 2 * NT * 8 * 64 * 4) + lane;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                __builtin_nontemporal_store(f32x4{L[4 * q], L[4 * q + 1], L[4 * q + 2], L[4 * q + 3]} * 1.4426950408889634f, &lp[(4 * t + q) * 64]);
+                if (!(ctrim && t == NT - 1 && q >= 2)) __builtin_nontemporal_store(f32x4{L[4 * q], L[4 * q + 1], L[4 * q + 2], L[4 * q + 3]} * 1.4426950408889634f, &lp[(4 * t + q) * 64]);
         }
         // Smix = S0 + (G_and - nb G_not) O + G_or L + G_chain Cr, one gate at a time
         f32x16 G3d = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -912,7 +916,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
                 typedef __attribute__((ext_vector_type(4))) unsigned int u4;
                 u4 *sp = (u4 *)(svb + SL.oSm + (size_t)w * NT * 8 * 64 * 4) + lane;
                 __builtin_nontemporal_store(u4{cw[0], cw[1], cw[2], cw[3]}, &sp[(2 * t) * 64]);
-                __builtin_nontemporal_store(u4{cw[4], cw[5], cw[6], cw[7]}, &sp[(2 * t + 1) * 64]);
+                if (!(ctrim && t == NT - 1)) __builtin_nontemporal_store(u4{cw[4], cw[5], cw[6], cw[7]}, &sp[(2 * t + 1) * 64]);
             }
         }
         if (!SAVE) {
@@ -937,7 +941,10 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
         const u4 *sp = (const u4 *)(svb + SL.oSm + (size_t)w * NT * 8 * 64 * 4) + lane;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const u4 lo = sp[(2 * t) * 64], hi = sp[(2 * t + 1) * 64];
+            const bool tr1 = ctrim && t == NT - 1;
+            const u4 lo = sp[(2 * t) * 64];
+            u4 hi = sp[(2 * t + (tr1 ? 0 : 1)) * 64];
+            if (tr1) hi = u4{0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u};       // trimmed chunk: -inf (padding keys)
 #pragma unroll
             for (int p = 0; p < 4; ++p) { crp[t][p] = lo[p]; crp[t][4 + p] = hi[p]; }
         }

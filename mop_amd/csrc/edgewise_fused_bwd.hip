@@ -327,6 +327,11 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
     // and waits lgkmcnt(0) behind it: read -> wait -> MFMA per k-step); asm statements keep their order and LDS returns in order, so
     // before fragment f only the younger reads may be outstanding.
     const bool klast = N > NP - 16;        // N <= NP - 16: the last 16-wide k-step of every contraction over tokens is all padding
+    // ... and so is the last 16-B chunk of every packed slab (keys / queries NP - 16 .. NP - 1): it is neither stored nor loaded (7 % of
+    // every N x N stream at N = 197).  Loads of it re-read the neighbouring chunk (cache-hot, branch-free) and are zeroed.
+    const bool ctrim = HEAD == 0 && !klast;
+    auto trim_idx = [&](int c) -> int { return (ctrim && c == 2 * NT - 1) ? c - 1 : c; };         // chunk actually loaded
+    auto trim_val = [&](int c, u32x4 v) -> u32x4 { return (ctrim && c == 2 * NT - 1) ? u32x4{0, 0, 0, 0} : v; };
     auto gemm_stream = [&](bf16x8 (&Out)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
         gemm_stream_epi<NT>(Am + r * LDA + 8 * h, Bf, klast,
                             [&](int to) { return accumulate ? unpack_tile_bf(Out[to][0], Out[to][1]) : zero16(); },
@@ -343,7 +348,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) Bf[t][s] = as_b8(__builtin_nontemporal_load(&p[(2 * t + s) * 64]));
+            for (int s = 0; s < 2; ++s) Bf[t][s] = as_b8(trim_val(2 * t + s, __builtin_nontemporal_load(&p[trim_idx(2 * t + s) * 64])));
     };
     // Pk[to] (+)= Am rows . Bf   with the running sum kept as packed bf16 tiles
     auto gemm_acc_packed = [&](bf16x8 (&Pk)[NT][2], const unsigned short *Am, const bf16x8 (&Bf)[NT][2], bool accumulate) {
@@ -406,13 +411,13 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
         __builtin_amdgcn_sched_barrier(0);
         u32x4 *p = slot(s);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { __builtin_nontemporal_store(as_u4(Xp[t][0]), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(Xp[t][1]), &p[(2 * t + 1) * 64]); }
+        for (int t = 0; t < NT; ++t) { __builtin_nontemporal_store(as_u4(Xp[t][0]), &p[(2 * t) * 64]); if (!(ctrim && t == NT - 1)) __builtin_nontemporal_store(as_u4(Xp[t][1]), &p[(2 * t + 1) * 64]); }
     };
     auto slot_ld = [&](int s, bf16x8 (&Xp)[NT][2]) {
         __builtin_amdgcn_sched_barrier(0);
         const u32x4 *p = slot(s);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(__builtin_nontemporal_load(&p[(2 * t) * 64])); Xp[t][1] = as_b8(__builtin_nontemporal_load(&p[(2 * t + 1) * 64])); }
+        for (int t = 0; t < NT; ++t) { Xp[t][0] = as_b8(__builtin_nontemporal_load(&p[(2 * t) * 64])); Xp[t][1] = as_b8(trim_val(2 * t + 1, __builtin_nontemporal_load(&p[trim_idx(2 * t + 1) * 64]))); }
     };
     // "all fragments of this slab are needed here": without it hipcc sinks each load of a slot_ld next to the tile that consumes
     // it (to shorten live ranges), i.e. one exposed memory round trip per tile instead of one per slab
@@ -474,7 +479,9 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
     const uint32_t rowh = fa_drop_row(drop, bh, qi);
     auto p_tile = [&](int t) -> f32x16 {      // P tile from the parked Smix
         const u32x4 *p = slot(S_SM);
-        f32x16 x = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), __builtin_nontemporal_load(&p[(2 * t + 1) * 64]));
+        u32x4 xh = __builtin_nontemporal_load(&p[trim_idx(2 * t + 1) * 64]);
+        if (ctrim && t == NT - 1) xh = u32x4{0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u};       // trimmed chunk: Smix = -inf (padding keys)
+        f32x16 x = unpack_tile_h(__builtin_nontemporal_load(&p[(2 * t) * 64]), xh);
 #pragma unroll
         for (int g = 0; g < 16; ++g) x[g] = __expf(x[g] - mxrow) * invl;
         return x;
@@ -608,7 +615,9 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
                 const f32x4 *p = (const f32x4 *)(svb + SL.oL + (size_t)w * 2 * Cfg::SLOT) + lane;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 l4 = __builtin_nontemporal_load(&p[(4 * t + q) * 64]);
+                    const bool ltr = ctrim && t == NT - 1 && q >= 2;
+                    f32x4 l4 = __builtin_nontemporal_load(&p[(4 * t + (ltr ? q - 2 : q)) * 64]);
+                    if (ltr) l4 = f32x4{0.f, 0.f, 0.f, 0.f};
                     lse[4 * q] = l4[0] * 0.6931471805599453f; lse[4 * q + 1] = l4[1] * 0.6931471805599453f;
                     lse[4 * q + 2] = l4[2] * 0.6931471805599453f; lse[4 * q + 3] = l4[3] * 0.6931471805599453f;
                 }
@@ -626,7 +635,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
                 }
                 bf16x8 bl, bh;
                 pack_tile_bf(bl, bh, dir);
-                u32x4 *p = slot(X_DIR + v); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
+                u32x4 *p = slot(X_DIR + v); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); if (!(ctrim && t == NT - 1)) __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
             }
         }
         // pass 2: gate gradients.  terms: and -> O, or -> L = lse - S0, not -> -nb O, chain -> log C->
@@ -637,7 +646,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
             const f32x16 S0 = s_tile(qe, t);
             L = lse - S0;
             const u32x4 *pc = slot(S_CF);
-            Cr = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(pc[(2 * t + 1) * 64]));
+            Cr = unpack_tile_bf(as_b8(pc[(2 * t) * 64]), as_b8(trim_val(2 * t + 1, pc[trim_idx(2 * t + 1) * 64])));
 #pragma unroll
             for (int g = 0; g < 16; ++g) Cr[g] = __logf(Cr[g] + EPSC);
         }
@@ -657,7 +666,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
 #pragma unroll
                 for (int g = 0; g < 16; ++g) c3[g] = dS[g] * G[g];
                 pack_tile_bf(bl, bh, c3);
-                u32x4 *p = slot(X_C3); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
+                u32x4 *p = slot(X_C3); __builtin_nontemporal_store(as_u4(bl), &p[(2 * t) * 64]); if (!(ctrim && t == NT - 1)) __builtin_nontemporal_store(as_u4(bh), &p[(2 * t + 1) * 64]);
             }
             // gate-logit gradients enter two contractions over ~N^2 edges whose result is a small difference of large sums: dZ is
             // split into a bf16 value and its bf16 remainder (as a and b already are), so the products are fp32-accurate
@@ -1061,7 +1070,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
             const u32x4 *p = slot(S_CF);
             u32x4 buf[NT][2];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { buf[t][0] = p[(2 * t) * 64]; buf[t][1] = p[(2 * t + 1) * 64]; }
+            for (int t = 0; t < NT; ++t) { buf[t][0] = p[(2 * t) * 64]; buf[t][1] = trim_val(2 * t + 1, p[trim_idx(2 * t + 1) * 64]); }
             __syncthreads();
 #pragma unroll
             for (int t = 0; t < NT; ++t) image_tile(t, as_b8(buf[t][0]), as_b8(buf[t][1]));
@@ -1220,7 +1229,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
                 }
                 u32x4 buf[NT][2];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { buf[t][0] = __builtin_nontemporal_load(&p[(2 * t) * 64]); buf[t][1] = __builtin_nontemporal_load(&p[(2 * t + 1) * 64]); }
+                for (int t = 0; t < NT; ++t) { buf[t][0] = __builtin_nontemporal_load(&p[(2 * t) * 64]); buf[t][1] = trim_val(2 * t + 1, __builtin_nontemporal_load(&p[trim_idx(2 * t + 1) * 64])); }
                 lds_barrier();                     // previous readers of R are done
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -1301,7 +1310,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
                 // while tile t is computed (a rolled loop exposes one full L2/HBM round trip per iteration otherwise)
                 const u32x4 *pd = slot(X_DIR + v);
                 const unsigned short *ktb = KT + r * LDA + 8 * h;
-                u32x4 nd0 = __builtin_nontemporal_load(&pd[0]), nd1 = __builtin_nontemporal_load(&pd[64]);
+                u32x4 nd0 = __builtin_nontemporal_load(&pd[0]), nd1 = trim_val(1, __builtin_nontemporal_load(&pd[trim_idx(1) * 64]));
                 bf16x8 nk[DT][2];
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) { nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA]; nk[dt][1] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 16]; }
@@ -1315,7 +1324,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
                     {   // unconditional (the last iteration re-requests its own tile): a conditional prefetch makes the number of
                         // outstanding loads unknown at the join and every later s_waitcnt in the iteration becomes vmcnt(0)
                         const int tn = t + 1 < NT ? t + 1 : t;
-                        nd0 = __builtin_nontemporal_load(&pd[(2 * tn) * 64]); nd1 = __builtin_nontemporal_load(&pd[(2 * tn + 1) * 64]);
+                        nd0 = __builtin_nontemporal_load(&pd[(2 * tn) * 64]); nd1 = trim_val(2 * tn + 1, __builtin_nontemporal_load(&pd[trim_idx(2 * tn + 1) * 64]));
 #pragma unroll
                         for (int dt = 0; dt < DT; ++dt) {
                             nk[dt][0] = *(const bf16x8 *)&ktb[(32 * dt) * LDA + 32 * tn];
