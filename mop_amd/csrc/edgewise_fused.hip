@@ -933,7 +933,6 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     // ---------------- softmax over keys + P V0                         :551-554
     mxrow = fmaxf(mxrow, __shfl_xor(mxrow, 32, 64));
     float l = 0.f;
-    bf16x8 Pp[NT][2];
     const FaDrop drop = fa_drop(a.dropout_p, a.dropout_seed);      // attn_drop (:552): keep / (1 - p) on P; the row sum stays undropped
     const uint32_t rowh = fa_drop_row(drop, b * H + hh, qi);
     if (SAVE) {                           // Smix back from the wave's own S_SM export (L2-hot) rather than 56 registers held through the mix loop
@@ -949,8 +948,16 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
             for (int p = 0; p < 4; ++p) { crp[t][p] = lo[p]; crp[t][4 + p] = hi[p]; }
         }
     }
+    // P V0 tile by tile.  With the record (training) the probabilities enter the MFMAs as a bf16 value plus its bf16 remainder: the
+    // backward takes delta_i = sum_j P_ij dP_ij from y_base = P v0 (dy . y_base), and a y_base built from once-rounded P disagrees with
+    // the P the backward forms itself by 4e-3 per edge -- a row-wise bias in dSmix that the gate-head gradients (differences of N^2
+    // terms) magnify.
+    f32x16 pv[DT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int dt = 0; dt < DT; ++dt) pv[dt] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        bf16x8 ph[2], pl[2];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             float e0 = __expf(h2_lo(crp[t][p]) - mxrow), e1 = __expf(h2_hi(crp[t][p]) - mxrow);
@@ -959,22 +966,31 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
                 e0 = fa_drop_keep(drop, rowh, 32 * t + tile_row(2 * p, h)) ? e0 * drop.inv_keep : 0.f;
                 e1 = fa_drop_keep(drop, rowh, 32 * t + tile_row(2 * p + 1, h)) ? e1 * drop.inv_keep : 0.f;
             }
-            Pp[t][p >> 2][2 * (p & 3)] = (short)f2bf(e0);
-            Pp[t][p >> 2][2 * (p & 3) + 1] = (short)f2bf(e1);
+            const unsigned short h0 = f2bf(e0), h1 = f2bf(e1);
+            ph[p >> 2][2 * (p & 3)] = (short)h0;
+            ph[p >> 2][2 * (p & 3) + 1] = (short)h1;
+            if (SAVE) {
+                pl[p >> 2][2 * (p & 3)] = (short)f2bf(e0 - bf2f(h0));
+                pl[p >> 2][2 * (p & 3) + 1] = (short)f2bf(e1 - bf2f(h1));
+            }
         }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (2 * t + s < 2 * NT - 1 || klast) {
+                    const bf16x8 af = *(const bf16x8 *)&(VT0 + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
+                    pv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, ph[s], pv[dt], 0, 0, 0);
+                    if (SAVE) pv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, pl[s], pv[dt], 0, 0, 0);
+                }
+            }
+    }
     l += __shfl_xor(l, 32, 64);
     const float invl = 1.f / l;
     if (SAVE && h == 0) { float *rw = (float *)(svb + SL.oRow); rw[qi] = mxrow; rw[NP + qi] = invl; }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-        f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 af = *(const bf16x8 *)&(VT0 + r * LDA + 8 * h)[(32 * dt) * LDA + 32 * t + 16 * s];
-                if (2 * t + s < 2 * NT - 1 || klast) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Pp[t][s], acc, 0, 0, 0);
-            }
+        const f32x16 acc = pv[dt];
         if (qok) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {

@@ -36,7 +36,11 @@ def timed(m, n=20):
 
 if not small:
     print("eager   %.2f ms/step" % timed(model), flush=True)
-g = torch.cuda.make_graphed_callables(model, (x,))
+try:
+    g = torch.cuda.make_graphed_callables(model, (x,))
+except RuntimeError as e:       # a Python-level refusal to capture (an op the capture mode does not allow): the one case the test may skip
+    print("CAPTURE_UNSUPPORTED", repr(e)[:300], flush=True)
+    sys.exit(0)
 print("captured", flush=True)
 if not small:
     print("graphed %.2f ms/step" % timed(g), flush=True)
