@@ -154,11 +154,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=NS["B"], help="per-GPU batch (default = BASELINE config)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="per-GPU batch (default: the BASELINE config's -- 256 images for layer / vit, 8 sequences for quartet / whisper)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="layer", choices=["layer", "vit"],
+    ap.add_argument("--workload", default="layer", choices=["layer", "vit", "quartet", "whisper"],
                     help="layer: one EdgewiseMSA layer fwd+bwd (BASELINE.json configs[1], the metric's workload at every N); "
-                         "vit: ViT-MoP 5.4 M training step with AdamW (configs[2], 256 images per GPU)")
+                         "vit: ViT-MoP 5.4 M training step with AdamW (configs[2], 256 images per GPU); "
+                         "quartet: GPT-MoP CausalSelfAttention (Quartet) fwd+bwd at T=1024, d=768, 12 heads (configs[3]); "
+                         "whisper: Whisper-MoP encoder MultiheadSelfAttention fwd+bwd at T=3000, d=384, 6 heads, bf16 (configs[4], "
+                         "fixed per-GPU batch for the 1 -> N leg)")
     ap.add_argument("--graph", action="store_true",
                     help="vit workload only: replay the model's forward + backward as HIP graphs (torch.cuda.make_graphed_callables); "
                          "that step is launch-bound in eager mode (~270 launches for 3.3 ms of kernels)")
@@ -177,12 +181,24 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); they must agree")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist = None
+    if args.batch is None:
+        args.batch = NS["B"] if args.workload in ("layer", "vit") else 8
     if args.dry_run:
         return dry_run(args, world, rank)
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # first RCCL contact: a failure names the rank, the device and the error and ends this (fresh) process with a non-zero status
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            probe = torch.ones(1, device="cuda")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world, f"all-reduce of ones gave {probe.item()} on {world} ranks"
+        except Exception as e:      # noqa: BLE001 -- reported, then fatal
+            print(f"bench.py: RCCL start-up failed on rank {rank} (cuda:{local}, {torch.cuda.get_device_name(local)}): {e!r}",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(3)
 
     from mop_amd import ops
     from mop_amd.parallel import FlatGradBucket
@@ -203,6 +219,31 @@ def main():
             y = layer(x)
             y.backward(dy)
             if world > 1:  # one flat gradient bucket, one RCCL all-reduce over xGMI
+                bucket.allreduce_(average=True)
+    elif args.workload in ("quartet", "whisper"):
+        from mop_amd.nn import CausalSelfAttention, MultiheadSelfAttention, TransformerConfig
+        torch.manual_seed(0)
+        if args.workload == "quartet":
+            SIB = dict(T=1024, D=768, H=12)
+            mod = CausalSelfAttention(TransformerConfig(n_head=SIB["H"], n_embd=SIB["D"], block_size=SIB["T"], dropout=0.0))
+            with torch.no_grad():
+                mod.mixture.fill_(0.0)                 # de-degenerate the init: sigmoid(-5) makes Quartet a single path
+        else:
+            SIB = dict(T=3000, D=384, H=6)
+            mod = MultiheadSelfAttention(SIB["D"], SIB["H"], 0.0, False, causal=False)
+        mod = mod.cuda().to(dtype)
+        params = [p for p in mod.parameters()]
+        x = torch.randn(B, SIB["T"], SIB["D"], device="cuda", dtype=dtype, generator=g).requires_grad_(True)
+        dy = torch.randn(B, SIB["T"], SIB["D"], device="cuda", dtype=dtype, generator=g)
+        bucket = FlatGradBucket(params)
+
+        def step():
+            for p in params:
+                p.grad = None
+            x.grad = None
+            y = mod(x)
+            y.backward(dy)
+            if world > 1:
                 bucket.allreduce_(average=True)
     else:
         import torch.nn.functional as F
@@ -244,6 +285,15 @@ def main():
         dt = float(t.item())
     tim = ops.timing_results()
     ops.enable_timing(False)
+    ar_ms = None
+    if world > 1 and args.workload != "vit":           # the step's one collective alone (HIP events on the compute stream), for the scaling read-out
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            bucket.allreduce_(average=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 10
 
     if rank == 0:
         imgs = B * world * args.steps / dt
@@ -260,7 +310,33 @@ def main():
                              "dim": NS["D"], "heads": NS["H"], "views": NS["V"], "gate_rank": NS["r"],
                              "share_qkv": True, "gate_mode": "lowrank", "parallelism": par,
                              "grad_allreduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0}
+            out["config"]["grad_allreduce_ms"] = ar_ms
             out["roofline"] = roofline(tim, B, args.dtype)
+        elif args.workload in ("quartet", "whisper"):
+            T, D, H = SIB["T"], SIB["D"], SIB["H"]
+            dh = D // H
+            if args.workload == "quartet":
+                # two full score maps (the row z-normalisation needs every key of a row: 2 x 2 T^2 dh) + the causal half of P V (T^2 dh)
+                flop_fwd, key, kname = B * H * 5.0 * T * T * dh, "quartet", "qt_{stats,fwd}_kernel / qt_{rowsum,dq,dkv}_kernel (quartet_flash.hip)"
+                out["metric"] = "GPT-MoP QuartetAttention fwd+bwd sequences/sec"
+                wl = ("CausalSelfAttention(use_quartet) module fwd+bwd: 5 Linear projections + libmopk Quartet core + o_proj, T=1024, d=768, "
+                      "12 heads, causal (BASELINE.json configs[3])")
+            else:
+                flop_fwd, key, kname = B * H * 4.0 * T * T * dh, "sdpa", "sdpa_flash_{fwd,dq,dkv}_kernel (sdpa_flash.hip)"
+                out["metric"] = "Whisper-MoP encoder attention fwd+bwd sequences/sec"
+                wl = ("MultiheadSelfAttention module fwd+bwd: q/k/v/o Linears + libmopk SDPA core, T=3000 (80 x 3000 mel frames), d=384, "
+                      "6 heads, non-causal (BASELINE.json configs[4]); fixed per-GPU batch")
+            out["unit"] = "sequences/s"
+            out["config"] = {"workload": wl, "per_gpu_batch": B, "tokens": T, "dim": D, "heads": H, "parallelism": par,
+                             "grad_allreduce_bytes": 4 * sum(p.numel() for p in params) if world > 1 else 0, "grad_allreduce_ms": ar_ms}
+            fm = sum(tim.get(key + "_fwd", [0.0])) / max(1, len(tim.get(key + "_fwd", [])))
+            bm = sum(tim.get(key + "_bwd", [0.0])) / max(1, len(tim.get(key + "_bwd", [])))
+            ach = (flop_fwd * 3.5) / ((fm + bm) * 1e-3) / 1e12 if fm + bm > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_BF16_TFLOPS, "traffic": None, "launch_ms": fm + bm,
+                               "algorithmic_flop_per_launch": flop_fwd * 3.5,
+                               "note": "attention core forward + backward (backward = 2.5 x the forward's flops), HIP events on the launch stream",
+                               "fwd": {"launch_ms": fm, "achieved": flop_fwd / (fm * 1e-3) / 1e12 if fm > 0 else 0.0}}
         else:
             out["metric"] = "ViT-MoP 5.4M training images/sec"
             out["config"] = {"workload": "ViT_MoP(dim 384, depth 3, heads 6, 100 classes) training step on 32x32 images: fwd + bwd + "
@@ -281,15 +357,23 @@ def roofline(tim, B, dtype):
     events on the launch stream; `traffic` = fabric bytes of those launches from the committed PMC passes (profiles/)."""
     fwd_ms = sum(tim.get("edgewise_fwd", [0.0])) / max(1, len(tim.get("edgewise_fwd", [])))
     bwd_ms = sum(tim.get("edgewise_bwd", [0.0])) / max(1, len(tim.get("edgewise_bwd", [])))
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if os.path.exists(tpath) and B == NS["B"] and dtype == "bf16":
-        tj = json.load(open(tpath))
-        traffic = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in tj.items() if "ew_fused_bwd_kernel" in k) or None
+    # `traffic` comes from separate rocprofv3 --pmc passes (tools/collect_profiles.sh), not from this run: the newest committed file is
+    # used only while it is not older than the kernel sources it describes, and its name travels in `traffic_source`
+    traffic, tsrc = None, None
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if cands and B == NS["B"] and dtype == "bf16":
+        tpath = cands[-1]
+        srcs = [os.path.join(ROOT, "mop_amd", "csrc", f) for f in ("edgewise_fused_bwd.hip", "bwd_common.h", "fused_common.h")]
+        stale = os.environ.get("MOPK_TRAFFIC_ANY") is None and any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(tpath) + 1 for f in srcs)
+        if not stale:
+            tj = json.load(open(tpath))
+            traffic = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in tj.items() if "ew_fused_bwd_kernel" in k) or None
+            tsrc = os.path.basename(tpath)
     ach = B * CORE_FLOP_BWD / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
     ach_fwd = B * CORE_FLOP_FWD / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
     return {"bound": "mfma", "kernel": "ew_fused_bwd_kernel<.., 0|1|2> (backward core: 3 launches)", "achieved": ach,
-            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_source": tsrc,
             "launch_ms": bwd_ms, "algorithmic_flop_per_launch": B * CORE_FLOP_BWD,
             "fwd": {"kernel": "ew_fused_fwd_kernel", "launch_ms": fwd_ms, "achieved": ach_fwd, "frac": ach_fwd / PEAK_BF16_TFLOPS},
             "core_fwd_bwd_frac": (B * (CORE_FLOP_FWD + CORE_FLOP_BWD) / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
@@ -305,6 +389,12 @@ def dry_run(args, world, rank):
         dist.init_process_group("gloo")
     if args.workload == "layer":
         model = build_layer_cpu()
+    elif args.workload == "quartet":
+        from mop_amd.nn import CausalSelfAttention, TransformerConfig
+        model = CausalSelfAttention(TransformerConfig(n_head=12, n_embd=768, block_size=1024, dropout=0.0))
+    elif args.workload == "whisper":
+        from mop_amd.nn import MultiheadSelfAttention
+        model = MultiheadSelfAttention(384, 6, 0.0, False, causal=False)
     else:
         from mop_amd.nn import ViT_MoP
         torch.manual_seed(0)

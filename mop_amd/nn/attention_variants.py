@@ -12,11 +12,12 @@ checkpoints load with `load_state_dict` and call sites need no change:
 
 Only the Linear projections run in PyTorch (hipBLASLt); everything between the
 qkv projection and the output projection is one C-ABI call (mop_amd/ops.py).
-The dense gate head (use_k3 included) and the S lens bank run inside the library's
-generic path; the Q/K lens bank's depthwise token convolutions (:472-498) are torch
-ops feeding per-view q/k to the same core.  Variants the kernels do not cover raise
-NotImplementedError instead of silently decomposing: masked Edgewise (NaN in the
-reference, SURVEY.md 8a note), attention dropout in training.
+The plain dense gate head runs on the fused kernels like the low-rank head; `use_k3` and the S lens bank run inside the library's
+generic path; the Q/K lens bank's depthwise token convolutions (:472-498) are torch ops feeding per-view q/k to the same core.
+An `attn_mask` on EdgewiseMSA is an extension (the reference is NaN there, SURVEY.md 8a note): the mask acts on the probabilities
+only, generic path.  Attention dropout (`attn_drop > 0` in training mode) runs inside every fused kernel family; the combinations
+that fall to the generic path (use_k3 / lens Edgewise, masked Edgewise, CrossViewMixer with cues or prior) raise
+NotImplementedError for it instead of training without dropout ("Dropout").
 """
 from __future__ import annotations
 

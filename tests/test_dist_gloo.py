@@ -123,7 +123,8 @@ def _bench(*argv, env=None, timeout=600):
     return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("workload,nbytes", [("layer", 4 * 596001), ("vit", 4 * 5397972)])
+@pytest.mark.parametrize("workload,nbytes", [("layer", 4 * 596001), ("vit", 4 * 5397972), ("quartet", 4 * (6 * 768 * 768 + 2)),
+                                             ("whisper", 4 * 4 * 384 * 384)])
 def test_bench_self_launch_two_ranks_gloo(workload, nbytes):
     """`python bench.py --gpus 2` as a plain command: bench.py starts the ranks itself (torch.distributed.run, 127.0.0.1), every rank
     all-reduces ONE flat gradient bucket of the workload's real size per step, rank 0 prints one JSON line (CPU rehearsal: gloo)."""
