@@ -554,6 +554,33 @@ def test_quartet_vs_oracle_at_gpt_sequence_length():
     assert abs(float(qsg.grad) - float(g["dquartet_scale"])) <= 5e-2 * max(abs(float(g["dquartet_scale"])), 1e-3 * float(np.abs(g["dv"]).max()) * T)
 
 
+def test_multihop_vs_oracle_at_gpt_sequence_length():
+    """config 4, second reading: the literal softmax(S1 + S2) kernel -- MultiHopMSA(768, 12) core with a causal mask at
+    seq 1024 (attention_variants.py:200-229), here one sequence and two heads of dk = 64, against the float64 oracle on the bf16-rounded
+    operands the kernel reads."""
+    from oracle import multihop as om
+    from mop_amd import ops, _lib
+    torch.manual_seed(6)
+    B, T, H, dk, hops = 1, 1024, 2, 64, 3
+    t = [torch.randn(B, T, H, dk, device="cuda").to(torch.bfloat16) for _ in range(6)]
+    dy = torch.randn(B, T, H * dk, device="cuda").to(torch.bfloat16)
+    logit = torch.tensor(-2.0, device="cuda")
+    tg = [a.clone().requires_grad_(True) for a in t]
+    lg = logit.clone().requires_grad_(True)
+    y = ops.dualpath_core(tg[0], tg[1], tg[2], tg[3], tg[4], tg[5], lg, 1.0, 0.0, 0.0, 0.0, 0.5, hops, None, True)
+    y.backward(dy)
+    assert ops.LAST_PATH["dualpath_fwd"] == _lib.PATH_FUSED
+    hp = lambda a: np.transpose(a.detach().float().cpu().numpy().astype(np.float64), (0, 2, 1, 3))     # (B,T,H,dk) -> (B,H,T,dk)
+    blocked = ~np.tril(np.ones((T, T), dtype=bool))
+    yo, c = om.core_fwd(*(hp(a) for a in t), dict(and_=1.0, or_=0.0, not_=0.0, chain=0.0), 0.5, hops, -2.0, blocked)
+    g = om.core_bwd(hp(dy.view(B, T, H, dk)), c)
+    yk = hp(y.view(B, T, H, dk))
+    assert max_abs(yk, yo) <= 1e-2 * max(1.0, float(np.abs(yo).max())), f"y {max_abs(yk, yo):.3e}"
+    for got, nm in ((tg[0].grad, "dq1"), (tg[1].grad, "dk1"), (tg[2].grad, "dv1"), (tg[3].grad, "dq2"), (tg[4].grad, "dk2"), (tg[5].grad, "dv2")):
+        assert rel_err(hp(got), g[nm]) <= 3e-2, f"{nm} {rel_err(hp(got), g[nm]):.3e}"
+    assert abs(float(lg.grad) - float(g["dlogit"])) <= 5e-2 * max(abs(float(g["dlogit"])), 1e-3 * float(np.abs(g["dv1"]).max()) * T)
+
+
 def test_sdpa_vs_oracle_at_whisper_sequence_length():
     """config 5 slice: T = 3000, dk = 64, two heads, non-causal SDPA (whisper_mop.py:137-177) against the float64 oracle."""
     from oracle import sdpa as osd
