@@ -72,7 +72,11 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
     auto slot = [&](int s) -> u32x4 * {
         if (s < X_C3)                                                        // read-only: the forward's copies
             return (u32x4 *)(svb + (s == S_CF ? SL.oCF : s == S_CB ? SL.oCB : s == S_SM ? SL.oSm : SL.oL) + (size_t)w * Cfg::SLOT) + lane;
-        return (u32x4 *)(xf + W.xSlots + ((size_t)(s - X_C3) * NT + w) * Cfg::SLOT) + lane;
+#ifdef MOPK_DEBUG_SLOTS      // diagnostic builds (tools/build_variant.py ... "-DMOPK_DEBUG_SLOTS"): a slab id outside this launch's hand-off region traps here
+        if (s < 0 || s - X_C3 >= X_COUNT(V, HEAD == 1)) __builtin_trap();
+#endif
+        const size_t idx = (size_t)(unsigned)(s - X_C3) * (size_t)NT + (size_t)w;      // every slab offset in size_t
+        return (u32x4 *)(xf + W.xSlots + idx * Cfg::SLOT) + lane;
     };
     // slot layout: [(t*2+s)][lane] u32x4  -> one coalesced 1 KiB store per (t,s)
 
