@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 114 /* 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
+#define MOPK_VERSION 115 /* 115: mask tensors on the fused dual-path kernels; 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -189,7 +189,7 @@ size_t mopk_dualpath_saved_bytes(const MopkDualPathArgs *a);
 size_t mopk_dualpath_workspace_bytes(const MopkDualPathArgs *a);
 int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream);
 int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream);
-/* 1 if MOPK_PATH_AUTO runs this call on the fused kernels: bf16 arithmetic, dk 32/64, chain gate 0, no mask tensor (causal flag ok) */
+/* 1 if MOPK_PATH_AUTO runs this call on the fused kernels: bf16 arithmetic, dk 32/64, chain gate 0 (causal flag and mask tensor ok) */
 int mopk_dualpath_fused_supported(const MopkDualPathArgs *a);
 
 /* --------------------------------------------------------------------------

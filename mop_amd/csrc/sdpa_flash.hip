@@ -398,9 +398,9 @@ size_t sdpa_flash_ws_bytes(const MopkSdpaArgs *a) { return (size_t)a->B * a->H *
         else { if (a->dk == 64) FA_LAUNCH4(KERNEL, 64, float, DUAL_, MB_, GRID, __VA_ARGS__);                    \
                else FA_LAUNCH4(KERNEL, 32, float, DUAL_, MB_, GRID, __VA_ARGS__); }                              \
     } while (0)
-// explicit mask / bias tensors exist for the plain (non-DUAL) kernels only
+// explicit mask / bias tensors: MB instantiations (plain and DUAL: the mask acts on the mixed logits, attention_variants.py:219-220)
 #define FA_DISPATCH(KERNEL, DUAL_, GRID, ...)                                                                  \
-    do { if (!(DUAL_) && (a->mask || a->bias)) FA_DISPATCH5(KERNEL, false, true, GRID, __VA_ARGS__);            \
+    do { if (a->mask || a->bias) FA_DISPATCH5(KERNEL, DUAL_, true, GRID, __VA_ARGS__);                          \
          else FA_DISPATCH5(KERNEL, DUAL_, false, GRID, __VA_ARGS__); } while (0)
 
 int sdpa_flash_fwd(const MopkSdpaArgs *a, hipStream_t st) {
@@ -457,6 +457,7 @@ static MopkSdpaArgs dp_sdpa(const MopkDualPathArgs *a) {
     MopkSdpaArgs s{};
     s.B = a->B; s.H = a->H; s.N = a->N; s.dk = a->dk; s.io_dtype = a->io_dtype; s.precision = MOPK_PREC_BF16; s.path = MOPK_PATH_FUSED;
     s.causal = a->causal;
+    s.mask = a->mask; s.mask_sb = a->mask_sb; s.mask_sh = a->mask_sh; s.mask_si = a->mask_si;      // every pass (A1, A2 and the mixed weights) sees it: :202-207, :219-220
     return s;
 }
 // element (b,h,n,d) of a strided view
@@ -528,7 +529,7 @@ __global__ void dp_dlogit_kernel(MopkView4 dy, MopkView4 yc, const float *logit,
 }  // namespace
 
 int dp_flash_supported(const MopkDualPathArgs *a, bool bwd) {
-    if (a->g_chain != 0.f || a->mask) return 0;                    // chain gate needs the N x N product A1 A2^(h-1): generic path
+    if (a->g_chain != 0.f) return 0;                               // chain gate needs the N x N product A1 A2^(h-1): generic path
     MopkSdpaArgs s = dp_sdpa(a);
     s.q = a->q1; s.k = a->k1; s.v = a->v1; s.y = a->y;
     if (bwd) { s.dy = a->dy; s.dq = a->dq1; s.dk_ = a->dk1; s.dv = a->dv1; }

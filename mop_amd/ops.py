@@ -660,7 +660,7 @@ def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, an
         return _empty_batch(q1, 0, q1.shape[1], q1.shape[2] * q1.shape[3])
     prec = _prec_for(q1.dtype)
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
-    if (prior_weight <= 0.0 and t1 == 0.0 and t2 == 0.0 and attn_mask is None and _PATH != L.PATH_GENERIC and prec == L.PREC_BF16
+    if (prior_weight <= 0.0 and t1 == 0.0 and t2 == 0.0 and _PATH != L.PATH_GENERIC and prec == L.PREC_BF16
             and q1.shape[-1] in (32, 64)):
         # S = q1 (m11 k1 + m12 k2)^T + q2 (m21 k1 + m22 k2)^T: the 2x2 mix folds into two mixed key tensors (autograd carries
         # d mix, d k1, d k2) and the core is the fused two-score attention (dual-path kernels without the transport term)
@@ -669,10 +669,10 @@ def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, an
         k2p = (m[1, 0] * k1 + m[1, 1] * k2).contiguous()
         zero = q1.new_zeros((), dtype=torch.float32)
         LAST_PATH["crossview_fwd"] = L.PATH_FUSED
-        return _DualPathFn.apply(q1, k1p, v1, q2, k2p, v1, zero, (1.0, 0.0, 0.0, 0.0), 0.0, 0, None, causal, prec, L.PATH_FUSED, drop)
+        return _DualPathFn.apply(q1, k1p, v1, q2, k2p, v1, zero, (1.0, 0.0, 0.0, 0.0), 0.0, 0, attn_mask, causal, prec, L.PATH_FUSED, drop)
     if drop[0] > 0:
         raise NotImplementedError("attn_drop > 0 in training mode: CrossViewMixerMSA carries it on its fused path only (no transpose "
-                                  "cues, no per-key prior, no mask tensor, bf16 arithmetic, dk 32/64)")
+                                  "cues, no per-key prior, bf16 arithmetic, dk 32/64)")
     LAST_PATH["crossview_fwd"] = L.PATH_GENERIC
     cfg = (float(t1), float(t2), float(prior_weight), int(prior_weight > 0.0), _ANCHOR_MODES.get(anchor_mode, 2), int(fixed_k_star))
     return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, prec)
@@ -703,7 +703,7 @@ class _DualPathFn(torch.autograd.Function):
             a.path = path
         if drop[0] > 0 and path != L.PATH_FUSED:
             raise NotImplementedError("attn_drop > 0 in training mode runs in the fused bf16 kernels only (dk 32/64, chain gate 0, "
-                                      "no mask tensor, bf16 arithmetic)")
+                                      "bf16 arithmetic)")
         a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         LAST_PATH["dualpath_fwd"] = path
         saved = _bytes(lib.mopk_dualpath_saved_bytes(C.byref(a)), dev)

@@ -227,7 +227,9 @@ def test_sdpa_flash_matches_generic_and_torch(shape):
 @pytest.mark.parametrize("cfg", [
     # B, N, H, dk, hops, (and, or, not), causal, io dtype
     (2, 197, 2, 64, 3, (1.0, 0.0, 0.0), False, torch.bfloat16), (1, 130, 3, 32, 2, (0.7, 0.4, 0.3), True, torch.bfloat16),
-    (2, 64, 2, 64, 4, (0.9, 0.5, 0.0), False, torch.float32), (1, 300, 1, 64, 3, (1.0, 0.0, 0.6), True, torch.float32)])
+    (2, 64, 2, 64, 4, (0.9, 0.5, 0.0), False, torch.float32), (1, 300, 1, 64, 3, (1.0, 0.0, 0.6), True, torch.float32),
+    # "mask": an explicit, non-triangular mask tensor (attention_variants.py:202-207, :219-220), per batch / broadcast over heads
+    (2, 150, 2, 64, 3, (1.0, 0.3, 0.0), "mask", torch.bfloat16), (1, 197, 3, 32, 2, (0.8, 0.0, 0.4), "mask", torch.float32)])
 def test_dualpath_fused_matches_generic(cfg):
     """MultiHopMSA core on the fused kernels (mixed logits in one pass, transport as chained passes) vs the generic path."""
     import mop_amd
@@ -237,12 +239,17 @@ def test_dualpath_fused_matches_generic(cfg):
     g = torch.Generator(device="cuda").manual_seed(N + hops)
     base = [torch.randn(B, N, H, dk, device="cuda", generator=g) for _ in range(6)]
     dy = torch.randn(B, N, H * dk, device="cuda", generator=g)
+    mask = None
+    if causal == "mask":
+        mask = (torch.rand(B, 1, N, N, device="cuda", generator=g) > 0.35)
+        mask |= torch.eye(N, dtype=torch.bool, device="cuda")            # every row keeps at least one key
+        causal = False
     res = {}
     for path in ("fused", "generic"):
         ops.set_path(path)
         ts = [t.to(dt).requires_grad_(True) for t in base]
         lg = torch.tensor(-0.3, device="cuda", requires_grad=True)
-        y = ops.dualpath_core(*ts, lg, g_and, g_or, g_not, 0.0, 0.6, hops, causal=causal)
+        y = ops.dualpath_core(*ts, lg, g_and, g_or, g_not, 0.0, 0.6, hops, mask, causal=causal)
         y.backward(dy.to(dt))
         res[path] = [y.float()] + [t.grad.float() for t in ts] + [lg.grad.float()]
         assert ops.LAST_PATH["dualpath_fwd"] == (_lib.PATH_FUSED if path == "fused" else _lib.PATH_GENERIC)
@@ -285,7 +292,7 @@ def test_quartet_fused_matches_generic(cfg):
         assert float((a_ - b_).abs().max()) / den <= (1e-2 if n_ == "y" else 5e-2), n_
 
 
-@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("causal", [False, True, "mask"])
 def test_crossview_fused_default_matches_generic(causal):
     """CrossViewMixerMSA without cues / prior: the 2x2 mix folds into two mixed key tensors + the fused two-score kernels."""
     import mop_amd
@@ -298,6 +305,8 @@ def test_crossview_fused_default_matches_generic(causal):
         m.mix.add_(0.3 * torch.randn(2, 2, device="cuda"))
     x = torch.randn(2, 150, 128, device="cuda")
     mask = torch.tril(torch.ones(150, 150, device="cuda")).view(1, 1, 150, 150) if causal else None
+    if causal == "mask":                             # an explicit non-triangular mask tensor runs on the fused path too
+        mask = ((torch.rand(2, 1, 150, 150, device="cuda") > 0.3) | torch.eye(150, dtype=torch.bool, device="cuda")).float()
     res = {}
     for path in ("auto", "generic"):
         ops.set_path(path)
