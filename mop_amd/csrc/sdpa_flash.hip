@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 2 : 3) sdpa_flash_fwd_kerne
     fa_block_id((N + FA_QB - 1) / FA_QB, qb, bh);
     const int b = bh / a.H, hh = bh % a.H;
     const int q0 = qb * FA_QB, qi = q0 + 32 * w + r;
+    const int wu = __builtin_amdgcn_readfirstlane(w);              // the wave index as a scalar (uniform branches on it)
     const bool qok = qi < N;
     const float c = rsqrtf((float)DK) * FA_LOG2E;                  // logits in base-2 units: exp2 without a multiply
     const IOT *kp = (const IOT *)a.k.ptr + b * a.k.sb + hh * a.k.sh, *vp = (const IOT *)a.v.ptr + b * a.v.sb + hh * a.v.sh;
@@ -112,6 +113,7 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 2 : 3) sdpa_flash_fwd_kerne
         __syncthreads();
         f32x16 S[2];
         float mx = FA_NEG;
+        const bool edge = k0 + FA_KT > N || (CAUSAL && k0 + FA_KT - 1 > q0 + 32 * wu);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             S[s2] = fa_mm_rows<DK>(Ks, 32 * s2, r, h, qe);
@@ -124,12 +126,15 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 2 : 3) sdpa_flash_fwd_kerne
 #pragma unroll
                 for (int g = 0; g < 16; ++g) { bool blk; S[s2][g] = fa_apply_mb(S[s2][g], mb, a, qi, k0 + 32 * s2 + tile_row(g, h), blk); }
             }
+            if (edge) {                         // wave-uniform: only tiles that touch the end of the keys or this wave's diagonal pay for the mask
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int j = k0 + 32 * s2 + tile_row(g, h);
-                S[s2][g] = (j >= N || (CAUSAL && j > qi)) ? FA_NEG : S[s2][g];      // select, not a branch around the element write
-                mx = fmaxf(mx, S[s2][g]);
+                for (int g = 0; g < 16; ++g) {
+                    const int j = k0 + 32 * s2 + tile_row(g, h);
+                    S[s2][g] = (j >= N || (CAUSAL && j > qi)) ? FA_NEG : S[s2][g];      // select, not a branch around the element write
+                }
             }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, S[s2][g]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx), alpha = __builtin_amdgcn_exp2f(m - mn);
