@@ -1353,7 +1353,11 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
 #pragma unroll
                     for (int g = 0; g < 16; ++g) {
                         const int j = 32 * t + tile_row(g, h);
-                        dS[g] = keep_if(j < N, A[g] * (dA[g] - dot) + dir[g] + drs + dmean[(V + v) * NP + j]);
+                        dS[g] = A[g] * (dA[g] - dot) + dir[g] + drs + dmean[(V + v) * NP + j];
+                    }
+                    if (32 * t + 32 > N) {            // only the tile that holds padding keys is masked (wave-uniform)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) dS[g] = keep_if(32 * t + tile_row(g, h) < N, dS[g]);
                     }
                     bf16x8 lo, hi;
                     pack_tile_bf(lo, hi, dS);
