@@ -907,8 +907,10 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
             for (int p = 0; p < 8; ++p) {
                 float s0 = fmaf(G[2 * p], h2_lo(cw[p]), S0[2 * p]);
                 float s1 = fmaf(G[2 * p + 1], h2_hi(cw[p]), S0[2 * p + 1]);
-                if (32 * t + tile_row(2 * p, h) >= N) s0 = -INFINITY;
-                if (32 * t + tile_row(2 * p + 1, h) >= N) s1 = -INFINITY;
+                if (32 * t + 32 > N) {              // wave-uniform: only the tile that holds padding keys is masked
+                    s0 = (32 * t + tile_row(2 * p, h) >= N) ? -INFINITY : s0;
+                    s1 = (32 * t + tile_row(2 * p + 1, h) >= N) ? -INFINITY : s1;
+                }
                 mxrow = fmaxf(mxrow, fmaxf(s0, s1));
                 cw[p] = pack_h2(s0, s1);
             }

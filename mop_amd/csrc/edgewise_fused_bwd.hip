@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
                 for (int g = 0; g < 16; ++g) dP[g] = fa_drop_keep(drop, rowh, 32 * t + tile_row(g, h)) ? dP[g] * drop.inv_keep : 0.f;
             }
 #pragma unroll
-            for (int g = 0; g < 16; ++g) dS[g] = (32 * t + tile_row(g, h) < N) ? P[g] * (dP[g] - delta) : 0.f;
+            for (int g = 0; g < 16; ++g) dS[g] = P[g] * (dP[g] - delta);      // padding keys: the record holds Smix = -inf there, so P = 0 and with it dS
         }
         // pass 1: gates -> gA = G_and - nb G_not, g1 = G_or ; lse tile ; per-view direct score gradients
         //   dS_v(direct) = dSmix * (v == 0 ? 1 - g1 + g1 pi_0 : gA + g1 pi_v),  pi_v = exp(S_v - lse)   -> parked per view
