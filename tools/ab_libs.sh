@@ -1,7 +1,9 @@
 #!/bin/bash
-# dev tool (GPU box): same-box A/B of two prebuilt libraries mop_amd/libmopk_A.so / libmopk_B.so (ABAB order);
-# box-to-box variance of the core kernels (2-3 %) is larger than most single optimisations
-for v in A B A B; do
-  cp mop_amd/libmopk_$v.so mop_amd/libmopk.so
-  echo "== $v"; timeout -k 10 200 python tools/bench_modes.py 2>&1 | tail -2
+# dev tool (GPU box): interleaved A/B of libmopk variants (tools/build_variant.py) on bench.py: bash tools/ab_libs.sh <name> [<name> ...]
+# ("base" = mop_amd/libmopk.so); two rounds, one process per measurement
+for round in 1 2; do
+  for v in "$@"; do
+    if [ "$v" = base ]; then L=$PWD/mop_amd/libmopk.so; else L=$PWD/mop_amd/libmopk_$v.so; fi
+    printf "%-24s " "$v"; MOPK_LIB=$L python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), 'ms  bwd', round(d['roofline']['launch_ms'],3), ' fwd', round(d['roofline']['fwd']['launch_ms'],3))"
+  done
 done
