@@ -22,7 +22,7 @@
 
 #include "fused_common.h"
 
-#ifdef MOPK_WHATIF_NOBAR       // timing experiment only (results are wrong)
+#ifdef MOPK_WHATIF_NOBAR       // MOPK_WHATIF_*: timing experiments only (results are wrong); built with tools/build_variant.py, read with tools/stamps_fwd.py
 #define __syncthreads() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #endif
 #ifndef MOPK_PF

@@ -246,33 +246,6 @@ __device__ __forceinline__ void gemm_stream_epi(const unsigned short *am_lane, c
         if (k == NK - 1) epi(to, acc);
     });
 }
-// One output tile of the same product from a 32-row image PART (ring slot of the part-pipelined chains):  acc = init + part[r][:] . Bf.
-// `am_lane` = part + r * LDA + 8 * h.  The 2 NT A-fragment reads run PF ahead of the MFMAs behind counted waits, as above.
-template <int NT>
-__device__ __forceinline__ f32x16 gemm_part(const unsigned short *am_lane, const bf16x8 (&Bf)[NT][2], bool klast, f32x16 acc) {
-    constexpr int NK = 2 * NT, PF = NK < 4 ? NK : 4;
-    const unsigned abase = (unsigned)(uintptr_t)am_lane;
-    bf16x8 ring[PF];
-    static_for<0, PF>([&](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        bf16x8 tmp;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(abase), "i"(32 * f));
-        ring[f] = tmp;
-    });
-    static_for<0, NK>([&](auto fc) {
-        constexpr int k = decltype(fc)::value;
-        constexpr int pend = (NK - 1 - k) < (PF - 1) ? (NK - 1 - k) : (PF - 1);
-        bf16x8 af = ring[k % PF];
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(af) : "i"(pend));
-        if (k < NK - 1 || klast) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, Bf[k >> 1][k & 1], acc, 0, 0, 0);
-        if constexpr (k + PF < NK) {
-            bf16x8 tmp;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tmp) : "v"(abase), "i"(32 * (k + PF)));
-            ring[(k + PF) % PF] = tmp;
-        }
-    });
-    return acc;
-}
 // B fragments of the 32 x 32 identity in the accumulator's k order: D = X . I returns a packed tile X (lane = row, registers = columns)
 // transposed (lane = column, registers = rows) -- two MFMAs per tile, exact (every entry is one bf16 value times 1.0)
 __device__ __forceinline__ void identity_frags(bf16x8 &idl, bf16x8 &idh, int r, int h) {
