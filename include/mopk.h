@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 115 /* 115: mask tensors on the fused dual-path kernels; 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
+#define MOPK_VERSION 116 /* 116: MopkEdgewiseExt.{n_extra,row_extra,col_extra,d_row_extra,d_col_extra}; 115: mask tensors on the fused dual-path kernels; 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -98,6 +98,16 @@ typedef struct MopkEdgewiseExt {
     const float *W2, *b2;       /* edge_head.conv2 (4,16) / (4)                                     :255 */
     /* backward outputs, fully reduced on device (any may be NULL when the matching input is unused) */
     float *dlens_w, *dW1, *db1, *dW3, *db3, *dW2, *db2;
+    /* Extra feature channels of the LOW-RANK head on the FUSED path (gate_mode = 0, n_lens = 0): n_extra channels appended to the head's
+     * input behind the 2V + 2 built-in ones, given directly as their row / column means -- row_extra, col_extra: (B,H,n_extra,N) fp32,
+     * contiguous; Wr / Wc (dWr / dWc) are (4r, 2V + 2 + n_extra).  _bwd writes the gradient with respect to those values into
+     * d_row_extra / d_col_extra (same shape).  This is how the S lens bank :425-442, :523-533 reaches the fused kernels with the
+     * low-rank head: the row / column means of a depthwise dilated 3x3 convolution of S_v = Qe_v k^T are linear functionals of q and k
+     * (row sums of S over three column ranges, shifted by the dilation), which the caller evaluates without ever forming a plane
+     * (mop_amd/ops.py: lens_mean_features).  2V + 2 + n_extra <= 26. */
+    int32_t n_extra;
+    const float *row_extra, *col_extra;
+    float *d_row_extra, *d_col_extra;
 } MopkEdgewiseExt;
 
 typedef struct MopkEdgewiseArgs {

@@ -34,6 +34,7 @@ class EdgewiseExt(C.Structure):
         ("gate_mode", C.c_int32), ("use_k3", C.c_int32), ("n_lens", C.c_int32), ("lens_dil", C.c_int32 * MAX_LENS),
         ("lens_w", _fp), ("W1", _fp), ("b1", _fp), ("W3", _fp), ("b3", _fp), ("W2", _fp), ("b2", _fp),
         ("dlens_w", _fp), ("dW1", _fp), ("db1", _fp), ("dW3", _fp), ("db3", _fp), ("dW2", _fp), ("db2", _fp),
+        ("n_extra", C.c_int32), ("row_extra", _fp), ("col_extra", _fp), ("d_row_extra", _fp), ("d_col_extra", _fp),
     ]
 
 

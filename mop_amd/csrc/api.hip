@@ -46,6 +46,9 @@ static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
         if (dense && bwd && (!x->dW1 || !x->db1 || !x->dW2 || !x->db2 || (x->use_k3 && (!x->dW3 || !x->db3)))) return MOPK_ERR_BAD_ARG;
         // lens banks, the 3x3 convolution and every dense-head backward: generic path only (the fused forward takes the plain dense head)
         if (a->path == MOPK_PATH_FUSED && (x->n_lens > 0 || (dense && x->use_k3))) return MOPK_ERR_UNSUPPORTED;
+        // extra feature channels (given as row / column means): low-rank head on the fused path only
+        if (x->n_extra < 0 || (x->n_extra > 0 && (!x->row_extra || !x->col_extra || (bwd && (!x->d_row_extra || !x->d_col_extra))))) return MOPK_ERR_BAD_ARG;
+        if (x->n_extra > 0 && (dense || x->n_lens > 0 || a->path != MOPK_PATH_FUSED)) return MOPK_ERR_UNSUPPORTED;
     }
     if (!a->q.ptr || !a->k.ptr || !a->v0.ptr || !a->vL.ptr || !a->sqk || !a->vs0 || !a->vsL || !a->chain_logit || !a->saved ||
         !a->workspace)

@@ -44,7 +44,7 @@ struct BwdCfg {
         w.oV0s = o; o += a256((size_t)NP * DK * 2);
         w.oVLs = o; o += a256((size_t)NP * DK * 2);
         w.oDbp = o; o += a256((size_t)NT * 16 * NP * 4);
-        w.oDW = o; o += a256((size_t)2 * 16 * 20 * 4);
+        w.oDW = o; o += a256((size_t)2 * 16 * WST * 4);
         w.stride = a256(o);
         w.xbase = w.base + w.stride * (size_t)nwg;
         size_t x = 0;
@@ -60,7 +60,7 @@ struct BwdCfg {
     }
     // LDS: R region | Ksm | floats
     static constexpr int GATE_BYTES = 4 * NP * BTS * 2 + 2 * 32 * LDA * 2 + NT * 32 * 40 * 2;   // bT | bmat | amat | tbuf
-    static constexpr int WSM_FLOATS = 2 * 16 * 19;                                                // gate-head weights + bias, row | col side
+    static constexpr int WSM_FLOATS = 2 * 16 * WST;                                               // gate-head weights + bias, row | col side
     static constexpr int R_BYTES = imax(imax(NP * LDA * 2, 3 * DP * LDA * 2), GATE_BYTES + WSM_FLOATS * 4);
     static constexpr int K_BYTES = F::K_BYTES;
     static __host__ __device__ constexpr int small_floats(int V) {

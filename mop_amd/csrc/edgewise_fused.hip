@@ -606,8 +606,10 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     FSTAMP();
     REFRESH();
     // ---------------- gate vectors                                     :323-326
-    const int C = 2 * V + 2;
-    float *Wsm = Cfg::WSM_EXTRA ? wsig + 8 : colpart;   // low-rank: [2][16][19] gate-head weights (+bias in slot 18); dense: W1^T [C][16], b1, W2^T [16][4], b2.  colpart is dead from here on
+    const int E = HEAD == 0 ? dw.E : 0;                  // extra feature channels of the low-rank head (given as row / column means)
+    const int C = 2 * V + 2 + E;
+    const float *rowx = dw.rowx + (size_t)blockIdx.x * (E * N), *colx = dw.colx + (size_t)blockIdx.x * (E * N);
+    float *Wsm = Cfg::WSM_EXTRA ? wsig + 8 : colpart;   // low-rank: [2][16][WST] gate-head weights (+bias in slot WST-1); dense: W1^T [C][16], b1, W2^T [16][4], b2.  colpart is dead from here on
     bf16x8 af4[4];                        // low-rank: a[g,k,i] as B fragments: slots [a_hi | a_lo | a_hi | 0]
     if constexpr (HEAD == 1) {
         // dense head weights, transposed so that one 16-byte LDS read yields the four values an inner loop needs:
@@ -622,7 +624,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
     for (int c = tid; c < 2 * 4 * R * (C + 1); c += NT * 64) {
         const int side = c / (4 * R * (C + 1)), rem = c % (4 * R * (C + 1)), o = rem / (C + 1), cc = rem % (C + 1);
         const float *Wg = side ? a.Wc : a.Wr, *bg = side ? a.bc : a.br;
-        Wsm[(side * 16 + o) * 19 + (cc < C ? cc : 18)] = cc < C ? Wg[o * C + cc] : bg[o];
+        Wsm[(side * 16 + o) * WST + (cc < C ? cc : WST - 1)] = cc < C ? Wg[o * C + cc] : bg[o];
     }
     LDS_BARRIER();
     for (int p = tid; p < 4 * NP; p += NT * 64) {          // b[g,k,j] -> bT[g][j][slots] = [b_hi | b_hi | b_lo | 0], one (j, g) per thread-iteration
@@ -630,19 +632,24 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
         unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
         if (j < N) {
             // the (up to) four rank channels of this gate side by side: four independent fma chains, every feature read once
-            const float *Wg4 = Wsm + (16 + g * R) * 19;
+            const float *Wg4 = Wsm + (16 + g * R) * WST;
             float sk[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sk[k] = Wg4[(k < R ? k : 0) * 19 + 18];
+            for (int k = 0; k < 4; ++k) sk[k] = Wg4[(k < R ? k : 0) * WST + WST - 1];
             for (int c = 0; c < V; ++c) {
                 const float fc = cS[c * NP + j], fr = rS[c * NP + j];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < R ? k : 0) * 19; sk[k] = fmaf(Wo[c], fc, fmaf(Wo[V + c], fr, sk[k])); }
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < R ? k : 0) * WST; sk[k] = fmaf(Wo[c], fc, fmaf(Wo[V + c], fr, sk[k])); }
             }
             {
                 const float f0 = cCr[j], f1 = cCl[j];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < R ? k : 0) * 19; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < R ? k : 0) * WST; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
+            }
+            for (int e = 0; e < E; ++e) {
+                const float fx = colx[e * N + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sk[k] = fmaf(Wg4[(k < R ? k : 0) * WST + 2 * V + 2 + e], fx, sk[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (k < R) { hi[k] = f2bf(sk[k]); lo[k] = f2bf(sk[k] - bf2f(hi[k])); }
@@ -655,20 +662,27 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) av16[g][k] = Wsm[(g * R + (k < R ? k : 0)) * 19 + 18];
+        for (int k = 0; k < 4; ++k) av16[g][k] = Wsm[(g * R + (k < R ? k : 0)) * WST + WST - 1];
     for (int c = 0; c < V; ++c) {
         const float fr = rS[c * NP + qi], fc = cS[c * NP + qi];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * R + (k < R ? k : 0)) * 19; av16[g][k] = fmaf(Wo[c], fr, fmaf(Wo[V + c], fc, av16[g][k])); }
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * R + (k < R ? k : 0)) * WST; av16[g][k] = fmaf(Wo[c], fr, fmaf(Wo[V + c], fc, av16[g][k])); }
     }
     {
         const float f0 = rCr[qi], f1 = rCl[qi];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * R + (k < R ? k : 0)) * 19; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * R + (k < R ? k : 0)) * WST; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
+    }
+    for (int e = 0; e < E; ++e) {
+        const float fx = qok ? rowx[e * N + qi] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) av16[g][k] = fmaf(Wsm[(g * R + (k < R ? k : 0)) * WST + 2 * V + 2 + e], fx, av16[g][k]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1025,8 +1039,9 @@ int MOPK_CAT(ew_fused_fwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     if (lds > 160 * 1024) return MOPK_ERR_UNSUPPORTED;
     const dim3 grid(a->B * a->H), block(NT * 64);
     const bool dense = a->ext && a->ext->gate_mode == 1;          // dense gate head (no 3x3, no lens): HEAD = 1, always with the full record
-    FusedDenseW dw{nullptr, nullptr, nullptr, nullptr};
-    if (dense) dw = FusedDenseW{a->ext->W1, a->ext->b1, a->ext->W2, a->ext->b2};
+    FusedDenseW dw{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (dense) { dw.W1 = a->ext->W1; dw.b1 = a->ext->b1; dw.W2 = a->ext->W2; dw.b2 = a->ext->b2; }
+    else if (a->ext && a->ext->n_extra > 0) { dw.E = a->ext->n_extra; dw.rowx = a->ext->row_extra; dw.colx = a->ext->col_extra; }
 #define MOPK_LAUNCH(IOT_, SAVE_, HEAD_) do {                                                                      \
         auto kfn = ew_fused_fwd_kernel<NT, DK, IOT_, SAVE_, HEAD_>;                                               \
         static int lds_set = 0;      /* per instantiation and per process: the attribute is sticky (and may not be set during stream capture) */ \
@@ -1066,6 +1081,10 @@ int ew_fused_fwd_supported(const MopkEdgewiseArgs *a) {
     if (a->ext && a->ext->gate_mode != 0) {                   // dense gate head: forward only, without the 3x3 convolution, full record
         if (a->ext->gate_mode != 1 || a->ext->use_k3 || !a->save_for_backward) return 0;
         if (!a->ext->W1 || !a->ext->b1 || !a->ext->W2 || !a->ext->b2) return 0;
+        if (a->ext->n_extra != 0) return 0;                   // extra feature channels: low-rank head only
+    }
+    if (a->ext && a->ext->n_extra != 0) {
+        if (a->ext->n_extra < 0 || 2 * a->V + 2 + a->ext->n_extra > WST - 1 || !a->ext->row_extra || !a->ext->col_extra) return 0;
     }
     if (a->q.sv != 0 || a->k.sv != 0) return 0;               // share_qkv only (per-view K restaging not built)
     if (pick_nt(a->N) == 0) return 0;

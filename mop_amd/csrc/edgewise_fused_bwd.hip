@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
     unsigned short *bmat = bT + 4 * NP * BTS;                         // [32][LDA] rows rho: b_hi (0-15) / b_lo (16-31), k-permuted cols
     unsigned short *amat = bmat + 32 * LDA;                           // [32][LDA] rows rho: a_hi / a_lo, k-permuted cols
     unsigned short *tbuf = amat + 32 * LDA;                           // [NT][32][40] per-wave 32x32 transpose buffer
-    float *Wsm = (float *)(smem + Cfg::GATE_BYTES);                    // [2][16][19] gate-head weights (+bias at [18]) staged per (b,h) for P3..P7
+    float *Wsm = (float *)(smem + Cfg::GATE_BYTES);                    // [2][16][WST] gate-head weights (+bias at [WST-1]) staged per (b,h) for P3..P7
     float *dav = (float *)R;                                          // [16][NP]  (after the mix-backward loop)
     float *dbv = dav + 16 * NP;                                       // [16][NP]
     unsigned short *Ksm = (unsigned short *)(smem + Cfg::R_BYTES);    // [NP][LDK]
@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
     // being hoisted to the kernel prologue and spilled (hipcc LICM + rematerialisation failure: ~1000 spills)
 #define REFRESH() do { asm volatile("" : "+v"(lane)); r = lane & 31; h = lane >> 5; qi = 32 * w + r; qok = qi < N; } while (0)
     const float invN = 1.f / (float)N;
-    const int C = 2 * V + 2;
+    const int E = (HEAD == 0 && PH == PH_A) ? dw.E : 0;     // extra feature channels of the low-rank head (row / column means from the caller)
+    const int C = 2 * V + 2 + E;
 
     unsigned char *ws = W.base + (size_t)blockIdx.x * W.stride;
     const FusedSavedLayout SL = fused_saved_layout<NT, DK>(a.N, a.V, true);
@@ -496,11 +497,12 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
     REFRESH();
     if constexpr (HEAD == 0) {
     // ================= P3: gate vectors =================
-    // gate-head weights -> LDS (row side [16][19], col side [16][19]; slot 18 = bias); R's tail is free from here to P7
+    // gate-head weights -> LDS (row side [16][WST], col side [16][WST]; slot WST-1 = bias); R's tail is free from here to P7
+    const float *rowx = dw.rowx + (size_t)bh * (E * N), *colx = dw.colx + (size_t)bh * (E * N);
     for (int c = tid; c < 2 * 4 * RK * (C + 1); c += NTH) {
         const int side = c / (4 * RK * (C + 1)), rem = c % (4 * RK * (C + 1)), o = rem / (C + 1), cc = rem % (C + 1);
         const float *Wg = side ? a.Wc : a.Wr, *bg = side ? a.bc : a.br;
-        Wsm[(side * 16 + o) * 19 + (cc < C ? cc : 18)] = cc < C ? Wg[o * C + cc] : bg[o];
+        Wsm[(side * 16 + o) * WST + (cc < C ? cc : WST - 1)] = cc < C ? Wg[o * C + cc] : bg[o];
     }
     __syncthreads();
     for (int p = tid; p < 4 * NP; p += NTH) {                  // b side: one (key j, gate g) pair per thread-iteration
@@ -509,19 +511,24 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
         unsigned short hi[4] = {0, 0, 0, 0}, lo[4] = {0, 0, 0, 0};
         if (j < N) {
             // the (up to) four rank channels of this gate side by side: four independent fma chains, every feature read once
-            const float *Wg4 = Wsm + (16 + g * RK) * 19;
+            const float *Wg4 = Wsm + (16 + g * RK) * WST;
             float sk[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sk[k] = Wg4[(k < RK ? k : 0) * 19 + 18];
+            for (int k = 0; k < 4; ++k) sk[k] = Wg4[(k < RK ? k : 0) * WST + WST - 1];
             for (int c = 0; c < V; ++c) {
                 const float fc = cS[c * NP + j], fr = rS[c * NP + j];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < RK ? k : 0) * 19; sk[k] = fmaf(Wo[c], fc, fmaf(Wo[V + c], fr, sk[k])); }
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < RK ? k : 0) * WST; sk[k] = fmaf(Wo[c], fc, fmaf(Wo[V + c], fr, sk[k])); }
             }
             {
                 const float f0 = cCr[j], f1 = cCl[j];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < RK ? k : 0) * 19; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
+                for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < RK ? k : 0) * WST; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
+            }
+            for (int e = 0; e < E; ++e) {
+                const float fx = colx[e * N + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sk[k] = fmaf(Wg4[(k < RK ? k : 0) * WST + 2 * V + 2 + e], fx, sk[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (k < RK) { hi[k] = f2bf(sk[k]); lo[k] = f2bf(sk[k] - bf2f(hi[k])); }
@@ -539,20 +546,27 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) av16[g][k] = Wsm[(g * RK + (k < RK ? k : 0)) * 19 + 18];
+        for (int k = 0; k < 4; ++k) av16[g][k] = Wsm[(g * RK + (k < RK ? k : 0)) * WST + WST - 1];
     for (int c = 0; c < V; ++c) {
         const float fr = rS[c * NP + qi], fc = cS[c * NP + qi];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * RK + (k < RK ? k : 0)) * 19; av16[g][k] = fmaf(Wo[c], fr, fmaf(Wo[V + c], fc, av16[g][k])); }
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * RK + (k < RK ? k : 0)) * WST; av16[g][k] = fmaf(Wo[c], fr, fmaf(Wo[V + c], fc, av16[g][k])); }
     }
     {
         const float f0 = rCr[qi], f1 = rCl[qi];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * RK + (k < RK ? k : 0)) * 19; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
+            for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * RK + (k < RK ? k : 0)) * WST; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
+    }
+    for (int e = 0; e < E; ++e) {
+        const float fx = qok ? rowx[e * N + qi] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) av16[g][k] = fmaf(Wsm[(g * RK + (k < RK ? k : 0)) * WST + 2 * V + 2 + e], fx, av16[g][k]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -740,6 +754,14 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
     {
         // dW partials first (they read rS/cS which dmean is about to overwrite)
         const int nO = 4 * RK;
+        float *xfeat = dbv + 16 * NP;                 // [2][E][NP] extra feature rows (row side, then col side), zero padded; behind dav | dbv, below Wsm
+        if (E) {
+            for (int c = tid; c < 2 * E * NP; c += NTH) {
+                const int sd = c / (E * NP), e = (c / NP) % E, n = c % NP;
+                xfeat[c] = n < N ? (sd ? colx : rowx)[e * N + n] : 0.f;
+            }
+            __syncthreads();
+        }
         for (int idx = tid; idx < 2 * nO * (C + 1); idx += NTH) {
             const int side = idx / (nO * (C + 1)), rem = idx % (nO * (C + 1));
             const int o = rem / (C + 1), c = rem % (C + 1);
@@ -751,6 +773,7 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
             else if (c < 2 * V) f = (side ? rS : cS) + (c - V) * NP;
             else if (c == 2 * V) f = side ? cCr : rCr;
             else if (c == 2 * V + 1) f = side ? cCl : rCl;
+            else if (c < C) f = xfeat + ((side ? E : 0) + c - (2 * V + 2)) * NP;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
             int n = 0;
             if (f) {         // 16-byte LDS reads (rows are 16-byte aligned): a quarter of the LDS instructions of the scalar loop
@@ -778,11 +801,20 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
                 for (int g4 = 0; g4 < 4; ++g4)          // o = g4 RK + k, rho = 4 g4 + k: nested so that no runtime division is needed
                     for (int k = 0; k < RK; ++k) {
                         const int o = g4 * RK + k, rho = 4 * g4 + k;
-                        sr = fmaf(Wsm[o * 19 + (cr >= 0 ? cr : 0)], dav[rho * NP + n], sr);
-                        sc = fmaf(Wsm[(16 + o) * 19 + (cc >= 0 ? cc : 0)], dbv[rho * NP + n], sc);
+                        sr = fmaf(Wsm[o * WST + (cr >= 0 ? cr : 0)], dav[rho * NP + n], sr);
+                        sc = fmaf(Wsm[(16 + o) * WST + (cc >= 0 ? cc : 0)], dbv[rho * NP + n], sc);
                     }
             const float dm = ((cr >= 0 ? sr : 0.f) + (cc >= 0 ? sc : 0.f)) * invN;
             xdmean[item] = dm;                // hand-off: PH_B / PH_C stage these vectors in their own LDS
+        }
+        // gradient with respect to the extra feature rows: straight to the caller (they are inputs of the kernel, not functions of q, k)
+        for (int item = tid; item < 2 * E * N; item += NTH) {
+            const int sd = item / (E * N), e = (item / N) % E, n = item % N;
+            const float *gv = sd ? dbv : dav, *Wx = Wsm + (sd ? 16 * WST : 0) + 2 * V + 2 + e;
+            float sx = 0.f;
+            for (int g4 = 0; g4 < 4; ++g4)
+                for (int k = 0; k < RK; ++k) sx = fmaf(Wx[(g4 * RK + k) * WST], gv[(4 * g4 + k) * NP + n], sx);
+            (sd ? dw.dcolx : dw.drowx)[(size_t)bh * (E * N) + e * N + n] = sx;
         }
         __syncthreads();
     }
@@ -1508,7 +1540,9 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     constexpr int NT = MOPK_INST_NT, DK = MOPK_INST_DK;
     using Cfg = BwdCfg<NT, DK>;
     const int lds = Cfg::lds_bytes(a_in->V);
-    if (lds > 160 * 1024 || 2 * a_in->V + 2 > 18) return MOPK_ERR_UNSUPPORTED;
+    const int n_extra = a_in->ext && a_in->ext->gate_mode == 0 ? a_in->ext->n_extra : 0;
+    if (lds > 160 * 1024 || 2 * a_in->V + 2 + n_extra > WST - 1) return MOPK_ERR_UNSUPPORTED;
+    if (n_extra && (!a_in->ext->row_extra || !a_in->ext->col_extra || !a_in->ext->d_row_extra || !a_in->ext->d_col_extra)) return MOPK_ERR_BAD_ARG;
     MopkEdgewiseArgs args = *a_in;
     if (!a_in->save_for_backward) {
         // small `saved`: rebuild the full record (chain + mix state) by running the forward in export mode into the workspace
@@ -1527,8 +1561,9 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
     const int nwgA = bwd_grid(a, 1), nwgB = bwd_grid(a, 2);
     const bool dense = bwd_dense(a);
     const BwdWs W = Cfg::carve(a->workspace, a->V, nwgB, a->B * a->H, dense);     // nwgB >= nwgA
-    FusedDenseW dw{nullptr, nullptr, nullptr, nullptr};
-    if (dense) dw = FusedDenseW{a->ext->W1, a->ext->b1, a->ext->W2, a->ext->b2};
+    FusedDenseW dw{nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (dense) { dw.W1 = a->ext->W1; dw.b1 = a->ext->b1; dw.W2 = a->ext->W2; dw.b2 = a->ext->b2; }
+    else if (n_extra) { dw.E = n_extra; dw.rowx = a->ext->row_extra; dw.colx = a->ext->col_extra; dw.drowx = a->ext->d_row_extra; dw.dcolx = a->ext->d_col_extra; }
     const dim3 block(NT * 64);
 #define MOPK_LAUNCH_H(IOT_, PH_, GRID_, HEAD_) do {                                                               \
         auto kfn = ew_fused_bwd_kernel<NT, DK, IOT_, PH_, HEAD_>;                                                 \
@@ -1552,10 +1587,10 @@ int MOPK_CAT(ew_fused_bwd_nt, MOPK_INST_NT, _dk, MOPK_INST_DK)(const MopkEdgewis
 }
 #else
 // sum the per-workgroup dW partials: out[idx] = sum_bh dwp[bh][idx]   (deterministic order)
-__global__ void ew_fused_dw_reduce_kernel(MopkEdgewiseArgs a, BwdWs W, int nwg) {
+__global__ void ew_fused_dw_reduce_kernel(MopkEdgewiseArgs a, BwdWs W, int nwg, int C) {
     // one block per output; 256 threads stride over the workgroups, fixed-shape tree reduction
     __shared__ float red[256];
-    const int nO = 4 * a.r, C = 2 * a.V + 2;
+    const int nO = 4 * a.r;
     const int idx = blockIdx.x;
     float s = 0.f;
     for (int g = threadIdx.x; g < nwg; g += 256) s += ((const float *)(W.base + (size_t)g * W.stride + W.oDW))[idx];
@@ -1569,8 +1604,9 @@ __global__ void ew_fused_dw_reduce_kernel(MopkEdgewiseArgs a, BwdWs W, int nwg) 
 }
 
 void ew_fused_dw_reduce(const MopkEdgewiseArgs *a, const BwdWs &W, int nwg, hipStream_t st) {
-    const int nout = 2 * 4 * a->r * (2 * a->V + 3);
-    hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3(nout), dim3(256), 0, st, *a, W, nwg);
+    const int C = 2 * a->V + 2 + (a->ext && a->ext->gate_mode == 0 ? a->ext->n_extra : 0);      // input channels of the head
+    const int nout = 2 * 4 * a->r * (C + 1);
+    hipLaunchKernelGGL(ew_fused_dw_reduce_kernel, dim3(nout), dim3(256), 0, st, *a, W, nwg, C);
 }
 // dense head: per-workgroup partials [[c][k] table: dW1[k][c] for c < C, row 15 = db1[k] | dW2^T [k][m] | db2[m]] -> conv1 / conv2 gradients
 struct DenseGradOut { float *dW1, *db1, *dW2, *db2; };

@@ -17,6 +17,7 @@ template <int B, int E, typename F> __device__ __forceinline__ void static_for(F
     }
 }
 constexpr int BTS = 24;         // bT row stride (ushorts): 16 k-slots + 8 pad (48 B, 16-B aligned)
+constexpr int WST = 27;         // row stride (floats) of the staged low-rank gate-head weights: up to 26 input channels + the bias in slot WST - 1
 
 __host__ __device__ constexpr int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int kperm16(int k) { return (k & 3) | ((k & 4) << 1) | ((k & 8) >> 1); }
@@ -31,8 +32,8 @@ struct FusedCfg {
     static constexpr int R_BYTES = imax(RING * PART * 2 + NP * LDK * 2, 2 * DP * LDA * 2 + 4 * NP * BTS * 2);
     static constexpr int K_BYTES = NP * LDK * 2;
     // fp32 scratch (floats): sqk sqk2 [8][DK] qbar kbar vs0 vsL [DK] | rCr rCl cCr cCl [NP] | colpart[NT][NP] | rS cS cst [V][NP] | wsig
-    // gate-head weights [2][16][19] are staged over colpart when it is large enough (NT = 7), else in their own slot
-    static constexpr int WSM_FLOATS = 2 * 16 * 19, WSM_EXTRA = NT * NP >= WSM_FLOATS ? 0 : WSM_FLOATS;
+    // gate-head weights [2][16][WST] are staged over colpart when it is large enough (NT = 7), else in their own slot
+    static constexpr int WSM_FLOATS = 2 * 16 * WST, WSM_EXTRA = NT * NP >= WSM_FLOATS ? 0 : WSM_FLOATS;
     static __host__ __device__ constexpr int small_floats(int V) {
         return 16 * DK + 4 * DK + 4 * NP + NT * NP + 2 * V * NP + 8 + WSM_EXTRA;
     }
@@ -201,8 +202,9 @@ __host__ __device__ inline bool fa_drop_keep(const FaDrop &d, uint32_t rowh, int
 }
 
 
-// device pointers of the dense gate head (MopkEdgewiseExt is a host struct): conv1 (16, C) / (16), conv2 (4, 16) / (4)
-struct FusedDenseW { const float *W1, *b1, *W2, *b2; };
+// device pointers taken from MopkEdgewiseExt (a host struct): the dense gate head's conv1 (16, C) / (16), conv2 (4, 16) / (4); and the
+// low-rank head's E extra feature channels as their row / column means (B,H,E,N) with the gradients' destinations
+struct FusedDenseW { const float *W1, *b1, *W2, *b2; int E; const float *rowx, *colx; float *drowx, *dcolx; };
 
 // ---- stream GEMM over an LDS operand image -------------------------------------------------------------------------------------
 // For every output tile `to`:  acc = init(to);  acc += Am[32 to + r][:] . Bf;  epi(to, acc).   `am_lane` = Am + r * LDA + 8 * h.

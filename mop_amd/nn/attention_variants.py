@@ -174,9 +174,9 @@ class EdgewiseMSA(nn.Module):
         if self.use_lens_bank and self.lens_kernel_size != 3:
             raise ValueError("lens_kernel_size must be 3: with padding = dilation any other size changes the plane size and "
                              "the reference's feature stack (:534) cannot be built")
-        if self.training and self.attn_drop.p > 0 and (self.use_lens_bank or (self.edge_head.gate_mode == "dense" and self.edge_head.use_k3)):
-            raise NotImplementedError("attn_drop > 0 in training mode: the fused kernels carry it (low-rank head, plain dense head); "
-                                      "the use_k3 / lens-bank variants (generic path) do not")
+        if self.training and self.attn_drop.p > 0 and self.edge_head.gate_mode == "dense" and (self.use_lens_bank or self.edge_head.use_k3):
+            raise NotImplementedError("attn_drop > 0 in training mode: the fused kernels carry it (low-rank head with or without the S lens "
+                                      "bank, plain dense head); the dense head's use_k3 / lens-bank variants (generic path) do not")
 
     def _qk_lens_views(self, qkv: torch.Tensor) -> torch.Tensor:
         """Q/K lens bank (:472-498): depthwise dilated convolutions over the token axis of view-0 q and k build one
@@ -232,11 +232,17 @@ class EdgewiseMSA(nn.Module):
             qkv = F.linear(x, w).view(B, N, V, 3, H, dk)
             sqk = torch.full((V, H, dk), inv, device=x.device, dtype=torch.float32)
             vs0 = vsL = torch.ones(H, dk, device=x.device, dtype=torch.float32)
-        if not dense and not self.use_lens_bank and attn_mask is None:
+        # low-rank head + S lens bank: the head reads row / column means only, and those of the lens planes have a closed form in q, k
+        # (ops.lens_mean_features) -- the fused kernels take them as extra feature channels, no N x N plane is ever convolved
+        lens_fused = (not dense and self.use_lens_bank and attn_mask is None and qkv.shape[2] == 1 and
+                      ops.lowrank_lens_fused_supported(qkv, n_s, eh.row_proj.weight.shape[0] // 4, len(self.lens_dilations)))
+        if not dense and attn_mask is None and (lens_fused or not self.use_lens_bank):
+            lens_w = torch.stack([c.weight[:, 0] for c in self.lens_bank]) if lens_fused else None           # (L,V,3,3)
             y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,
                                           eh.col_proj.weight.squeeze(-1), eh.col_proj.bias,
                                           self.chain_value_logit, float(self.beta_not), n_s,
-                                          dropout_p=float(self.attn_drop.p) if self.training else 0.0)      # :552
+                                          dropout_p=float(self.attn_drop.p) if self.training else 0.0,       # :552
+                                          lens_w=lens_w, lens_dilations=self.lens_dilations if lens_fused else ())
             return self._project(y, residual)
         # dense gate head and / or S lens bank: the library's generic path (MopkEdgewiseExt)
         lens_w = torch.stack([c.weight[:, 0] for c in self.lens_bank]) if self.use_lens_bank else None   # (L,S,3,3)

@@ -10,6 +10,7 @@ import ctypes as C
 from typing import Optional
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib as L
 
@@ -166,12 +167,16 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
     """y = EdgewiseMSA core(qkv, ...) ; reference attention_variants.py:500-562."""
 
     @staticmethod
-    def forward(ctx, qkv, sqk, vs0, vsL, Wr, br, Wc, bc, logit, beta_not, V, prec, path, want_bwd, drop=(0.0, 0)):
+    def forward(ctx, qkv, sqk, vs0, vsL, Wr, br, Wc, bc, logit, beta_not, V, prec, path, want_bwd, drop=(0.0, 0),
+                row_extra=None, col_extra=None):
+        """row_extra / col_extra: (B,H,E,N) row / column means of E extra feature channels of the head (Wr / Wc then have
+        2V + 2 + E input channels): fused path only (MopkEdgewiseExt.n_extra)."""
         _require_gpu(qkv, "EdgewiseMSA")
         lib = L.lib()
         B, N, Vq, _, H, dk = qkv.shape
         qkv = qkv.contiguous()
         dev = qkv.device
+        n_extra = 0 if row_extra is None else int(row_extra.shape[2])
         f = dict(zip(("sqk", "vs0", "vsL", "Wr", "br", "Wc", "bc", "logit"),
                      _f32_pack([sqk, vs0, vsL, Wr, br, Wc, bc, logit.reshape(1)])))
         ctx.small_dtype = sqk.dtype if len({t.dtype for t in (sqk, vs0, vsL, Wr, br, Wc, bc, logit)}) == 1 else None
@@ -186,6 +191,15 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         a.chain_logit = f["logit"].data_ptr()
         y = torch.empty(B, N, H, dk, dtype=qkv.dtype, device=dev)
         a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
+        extras = ()
+        if n_extra:
+            extras = (_f32c(row_extra), _f32c(col_extra))
+            ext = L.EdgewiseExt()
+            ext.n_extra, ext.row_extra, ext.col_extra = n_extra, extras[0].data_ptr(), extras[1].data_ptr()
+            a.ext = C.pointer(ext)
+            if path == L.PATH_GENERIC or not lib.mopk_edgewise_fused_supported(C.byref(a)):
+                raise NotImplementedError("extra feature channels are an input of the fused Edgewise kernels only")
+            path = L.PATH_FUSED
         if path == L.PATH_AUTO:   # AUTO: fused gfx950 kernels when they cover the shape, generic otherwise
             path = L.PATH_FUSED if lib.mopk_edgewise_fused_supported(C.byref(a)) else L.PATH_GENERIC
         a.path = path
@@ -204,14 +218,14 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         with _timed("edgewise_fwd"):
             rc = lib.mopk_edgewise_lowrank_fwd(C.byref(a), _stream())
         L.check(rc, "mopk_edgewise_lowrank_fwd")
-        ctx.save_for_backward(qkv, saved, *f.values())
+        ctx.save_for_backward(qkv, saved, *f.values(), *extras)
         ctx.meta = (beta_not, V, prec, path, r, int(a.save_for_backward), drop)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
-        qkv, saved, sqk, vs0, vsL, Wr, br, Wc, bc, logit = ctx.saved_tensors
+        qkv, saved, sqk, vs0, vsL, Wr, br, Wc, bc, logit, *extras = ctx.saved_tensors
         beta_not, V, prec, path, r, sfb, drop = ctx.meta
         B, N, Vq, _, H, dk = qkv.shape
         dev = qkv.device
@@ -233,7 +247,15 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         dqkv = (torch.empty_like(qkv) if Vq == 1 else torch.zeros_like(qkv))
         _ew_views(a, dqkv, "d")
         f32 = dict(dtype=torch.float32, device=dev)
-        C_ = 2 * V + 2
+        n_extra = extras[0].shape[2] if extras else 0
+        C_ = 2 * V + 2 + n_extra
+        d_extras = (None, None)
+        if n_extra:
+            d_extras = (torch.empty_like(extras[0]), torch.empty_like(extras[1]))
+            ext = L.EdgewiseExt()
+            ext.n_extra, ext.row_extra, ext.col_extra = n_extra, extras[0].data_ptr(), extras[1].data_ptr()
+            ext.d_row_extra, ext.d_col_extra = d_extras[0].data_ptr(), d_extras[1].data_ptr()
+            a.ext = C.pointer(ext)
         # per-batch partials of the small gradients, and ONE buffer for their final values (reduced by the library in a single
         # launch, cast to the parameters' dtype in a single kernel, handed to autograd as views)
         n_sqk, n_vs, n_w, n_b = V * H * dk, H * dk, 4 * r * C_, 4 * r
@@ -258,7 +280,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
             small = small.to(ctx.small_dtype)
             dsqk, dvs0, dvsL, dWr, dbr, dWc, dbc, dlg = torch.split(small, [n_sqk, n_vs, n_vs, n_w, n_b, n_w, n_b, 1])
         return (dqkv, dsqk.view(V, H, dk), dvs0.view(H, dk), dvsL.view(H, dk), dWr.view(4 * r, C_), dbr, dWc.view(4 * r, C_), dbc,
-                dlg.reshape(()), None, None, None, None, None, None)
+                dlg.reshape(()), None, None, None, None, None, None, *d_extras)
 
 
 class EdgewiseVariant:
@@ -437,20 +459,67 @@ def edgewise_general_core(qkv, sqk, vs0, vsL, chain_logit, head, beta_not: float
                                     e if lens_w is None else lens_w, beta_not, n_views, prec, variant, wants_grad, drop, attn_mask)
 
 
+def lens_mean_features(qkv, sqk, lens_w, dilations):
+    """Row / column means of the S lens bank's planes (reference attention_variants.py:523-533) WITHOUT the planes.
+
+    The bank convolves each score plane S_v = (q * sqk_v) k^T with a depthwise dilated 3x3 kernel w (zero padding = dilation d); the
+    low-rank head only ever sees row and column means of the result (:323-326), and those are linear functionals of q and k:
+        row mean [i] = 1/N sum_a sum_b w[a][b] R_b[i + (a-1) d],   R_b[i'] = q_v[i'] . sum_{j' in J_b} k[j']
+        col mean [j] = 1/N sum_a sum_b w[a][b] C_a[j + (b-1) d],   C_a[j'] = k[j'] . sum_{i' in J_a} q_v[i']
+    with J_0 = [0, N-d), J_1 = [0, N), J_2 = [d, N) the source rows / columns a kernel tap can reach.  O(N dk) work per (b, h, v)
+    in plain torch ops (autograd carries their backward into q, k, sqk and the lens weights).
+
+    qkv (B,N,1,3,H,dk) shared q / k; sqk (V,H,dk); lens_w (L,V,3,3); -> row, col (B,H,L*V,N) float32, channels l-major as :531."""
+    B, N, _, _, H, dk = qkv.shape
+    V = sqk.shape[0]
+    q = qkv[:, :, 0, 0].permute(0, 2, 1, 3).float()           # (B,H,N,dk)
+    k = qkv[:, :, 0, 1].permute(0, 2, 1, 3).float()
+    sq = sqk.float()
+    rows, cols = [], []
+    for l, d in enumerate(dilations):
+        lo = max(N - int(d), 0)                                 # |J_0| = |J_2|
+        ks = torch.stack([k[:, :, :lo].sum(2), k.sum(2), k[:, :, N - lo:].sum(2)], 2)        # (B,H,3,dk)
+        qs = torch.stack([q[:, :, :lo].sum(2), q.sum(2), q[:, :, N - lo:].sum(2)], 2)
+        w = lens_w[l].float() / N                                                           # (V,3,3) [a][b]
+        R = torch.einsum("bhid,vhd,bhsd->bhvsi", q, sq, ks).reshape(B * H, V * 3, N)
+        Cs = torch.einsum("bhjd,vhd,bhsd->bhvsj", k, sq, qs).reshape(B * H, V * 3, N)
+        rows.append(F.conv1d(R, w.permute(0, 2, 1).contiguous(), padding=int(d), dilation=int(d), groups=V).view(B, H, V, N))
+        cols.append(F.conv1d(Cs, w.contiguous(), padding=int(d), dilation=int(d), groups=V).view(B, H, V, N))
+    return torch.cat(rows, 2), torch.cat(cols, 2)
+
+
+def lowrank_lens_fused_supported(qkv, n_views: int, rank: int, n_lens: int, precision: Optional[int] = None) -> bool:
+    """True when the fused kernels take this low-rank call with an S lens bank of n_lens dilations (as extra mean-feature channels)"""
+    if not qkv.is_cuda or qkv.shape[2] != 1 or qkv.shape[0] == 0 or _PATH == L.PATH_GENERIC or qkv.dtype == torch.float16:
+        return False
+    B, N, _, _, H, dk = qkv.shape
+    a, ext = L.EdgewiseArgs(), L.EdgewiseExt()
+    a.B, a.H, a.N, a.dk, a.V, a.r = B, H, N, dk, n_views, rank
+    a.io_dtype, a.path = _io_dtype(qkv), L.PATH_FUSED
+    a.precision = _prec_for(qkv.dtype) if precision is None else precision
+    _ew_views(a, qkv, "")
+    a.y = L.View4(qkv.data_ptr(), N * H * dk, dk, H * dk)
+    ext.n_extra, ext.row_extra, ext.col_extra = n_lens * n_views, qkv.data_ptr(), qkv.data_ptr()      # non-null stand-ins: nothing is read
+    a.ext = C.pointer(ext)
+    return bool(L.lib().mopk_edgewise_fused_supported(C.byref(a)))
+
+
 @_half_via_fp32
 def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not: float,
                           n_views: int, precision: Optional[int] = None, path: Optional[int] = None,
-                          dropout_p: float = 0.0, seed: Optional[int] = None):
+                          dropout_p: float = 0.0, seed: Optional[int] = None, lens_w=None, lens_dilations=()):
     """qkv: (B,N,Vq,3,H,dk) with Vq in {1 (share_qkv), n_views}; returns (B,N,H*dk).  dropout_p > 0: attn_drop on the mixed
-    attention weights (:552) inside the fused kernels (see `sdpa_core`)."""
+    attention weights (:552) inside the fused kernels (see `sdpa_core`).  lens_w (L,V,3,3) + lens_dilations: the S lens bank, fed to
+    the fused kernels as extra mean-feature channels (`lens_mean_features`; callers check `lowrank_lens_fused_supported` first)."""
     if qkv.shape[0] == 0:
         return _empty_batch(qkv, 0, qkv.shape[1], qkv.shape[-2] * qkv.shape[-1])
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     prec = _prec_for(qkv.dtype) if precision is None else precision
     want_bwd = torch.is_grad_enabled() and any(
-        t.requires_grad for t in (qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit))
+        t is not None and t.requires_grad for t in (qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, lens_w))
+    extras = (None, None) if lens_w is None else lens_mean_features(qkv, sqk, lens_w, lens_dilations)
     return _EdgewiseLowrankFn.apply(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not,
-                                    n_views, prec, _PATH if path is None else path, want_bwd, drop)
+                                    n_views, prec, _PATH if path is None else path, want_bwd, drop, *extras)
 
 
 # --------------------------------------------------------------------------------------

@@ -104,10 +104,12 @@ def test_edgewise_variants_vs_reference_golden(name, prec):
     assert rel_err(dx, d["dx"]) <= gtol, f"dx rel {rel_err(dx, d['dx']):.3e}"
     check_grads(grads, gref, gtol, floor=1e-3 if prec == "fp32" else 1e-2, d=d if prec == "bf16" else None)
     if meta["gate_mode"] == "dense" or meta["use_lens_bank"]:
-        # the plain dense head (no 3x3, no lens bank, shared qkv) runs on the fused bf16 kernels; every other variant on the generic path
-        plain = (meta["gate_mode"] == "dense" and not meta["use_k3"] and not meta["use_lens_bank"] and not meta["use_lens_bank_qk"]
-                 and bool(meta["share_qkv"]))
-        want = _lib.PATH_FUSED if (plain and prec == "bf16") else _lib.PATH_GENERIC
+        # on the fused bf16 kernels (shared qkv, no Q/K lens bank): the plain dense head (no 3x3, no lens bank) and the low-rank head with
+        # the S lens bank (its planes enter as row / column means); every other variant on the generic path
+        shared = bool(meta["share_qkv"]) and not meta["use_lens_bank_qk"]
+        plain = meta["gate_mode"] == "dense" and not meta["use_k3"] and not meta["use_lens_bank"]
+        lr_lens = meta["gate_mode"] == "lowrank" and meta["use_lens_bank"]
+        want = _lib.PATH_FUSED if (shared and (plain or lr_lens) and prec == "bf16") else _lib.PATH_GENERIC
         assert ops.LAST_PATH["edgewise_fwd"] == want and ops.LAST_PATH["edgewise_bwd"] == want
 
 
@@ -462,6 +464,64 @@ def test_variants_vs_oracle_at_full_sequence_length(variant):
     assert max_abs(y, out) <= 1e-4, f"y {max_abs(y, out):.3e}"
     assert rel_err(dx, dx_ref) <= 1e-3, f"dx {rel_err(dx, dx_ref):.3e}"
     check_grads(grads, g_ref, 1e-3, floor=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(2, 197, 384, 6, 5, 2, (1, 2)), (3, 50, 128, 2, 3, 4, (1, 2, 3)), (1, 8, 64, 4, 2, 1, (1, 9)),
+                                   (2, 129, 64, 1, 4, 3, (2,)), (1, 224, 128, 4, 8, 2, (3,)), (2, 65, 64, 4, 2, 4, (1, 2, 4, 8))])
+def test_fused_lowrank_lens_bank_vs_oracle_and_generic(shape):
+    """Low-rank gate head + S lens bank (attention_variants.py:425-442, :523-533, :323-326) on the FUSED kernels: the lens planes reach the
+    head only as row / column means, which ops.lens_mean_features evaluates in closed form and the kernels take as extra feature channels
+    (MopkEdgewiseExt.n_extra).  Output and every gradient (lens weights included) against the float64 oracle on bf16-rounded inputs, next to
+    the generic path (which convolves the planes) on the same inputs."""
+    from oracle import edgewise as oe
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import EdgewiseMSA
+    B, N, D, H, V, r, dil = shape
+    torch.manual_seed(N * 11 + V)
+    m = EdgewiseMSA(D, H, n_views=V, share_qkv=True, gate_mode="lowrank", gate_rank=r, gate_init="mix5", use_lens_bank=True, lens_dilations=dil)
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("_scale"):
+                p.add_(0.1 * torch.randn_like(p))
+            if "proj.weight" in n_ and "edge_head" in n_:
+                p.mul_(3.0)
+        m.chain_value_logit.fill_(-0.5)
+    x, w = torch.randn(B, N, D), torch.randn(B, N, D)
+    rb = lambda t: torch.as_tensor(t).to(torch.bfloat16).double().numpy()
+    params = {k: rb(v) for k, v in m.state_dict().items()}
+    out, cache = oe.module_fwd(rb(x), params, H, V, True, 0.5, lens_dilations=dil)
+    dx_ref, g_ref = oe.module_bwd(rb(w), cache)
+    mop_amd.set_precision("bf16")
+    res = {}
+    for path in ("generic", "auto"):
+        ops.set_path(path)
+        mg = m.cuda().to(torch.bfloat16).eval()
+        mg.zero_grad()
+        res[path] = run_fwd_bwd(mg, rb(x), rb(w), dtype=torch.bfloat16)
+        want = _lib.PATH_FUSED if path == "auto" else _lib.PATH_GENERIC
+        assert ops.LAST_PATH["edgewise_fwd"] == want and ops.LAST_PATH["edgewise_bwd"] == want
+    y, dx, grads = res["auto"]
+    yg, dxg, gg = res["generic"]
+    assert max_abs(y, out) <= TOL_BF16, f"y {max_abs(y, out):.3e}"
+    assert rel_err(dx, dx_ref) <= GTOL_BF16, f"dx {rel_err(dx, dx_ref):.3e}"
+    assert set(grads) == set(g_ref)
+    for k in g_ref:          # per tensor: the bf16 bound, or twice what the generic path (same inputs, planes convolved in fp32) shows
+        e, eg = rel_err(grads[k].reshape(g_ref[k].shape), g_ref[k]), rel_err(gg[k].reshape(g_ref[k].shape), g_ref[k])
+        assert e <= max(GTOL_BF16, 2.0 * eg), f"{k}: fused {e:.3e} generic {eg:.3e}"
+
+
+def test_fused_lowrank_lens_bank_takes_dropout():
+    """attn_drop in training mode with the S lens bank: carried by the fused kernels (the generic path would refuse)"""
+    import mop_amd
+    from mop_amd import ops, _lib
+    from mop_amd.nn import EdgewiseMSA
+    torch.manual_seed(5)
+    m = EdgewiseMSA(128, 2, n_views=3, share_qkv=True, gate_mode="lowrank", gate_rank=2, use_lens_bank=True, attn_drop=0.2).cuda().to(torch.bfloat16).train()
+    x = torch.randn(2, 40, 128, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    m(x).float().sum().backward()
+    assert ops.LAST_PATH["edgewise_fwd"] == _lib.PATH_FUSED and torch.isfinite(x.grad).all()
+    assert all(torch.isfinite(c.weight.grad).all() and float(c.weight.grad.abs().max()) > 0 for c in m.lens_bank)
 
 
 @pytest.mark.parametrize("shape", [(2, 197, 384, 6, 5), (3, 50, 128, 2, 3), (1, 8, 64, 4, 2), (2, 129, 64, 1, 4), (1, 224, 128, 4, 8), (2, 65, 128, 2, 5)])
