@@ -646,10 +646,12 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < R ? k : 0) * WST; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
             }
-            for (int e = 0; e < E; ++e) {
-                const float fx = colx[e * N + j];
+            for (int e0 = 0; e0 < E; e0 += XU) {
+                float fx[XU];
+                load_extra(fx, colx, N, j, e0, E, true);
+                for (int u = 0; u < XU && e0 + u < E; ++u)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sk[k] = fmaf(Wg4[(k < R ? k : 0) * WST + 2 * V + 2 + e], fx, sk[k]);
+                    for (int k = 0; k < 4; ++k) sk[k] = fmaf(Wg4[(k < R ? k : 0) * WST + 2 * V + 2 + e0 + u], fx[u], sk[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (k < R) { hi[k] = f2bf(sk[k]); lo[k] = f2bf(sk[k] - bf2f(hi[k])); }
@@ -677,12 +679,14 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_fwd_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * R + (k < R ? k : 0)) * WST; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
     }
-    for (int e = 0; e < E; ++e) {
-        const float fx = qok ? rowx[e * N + qi] : 0.f;
+    for (int e0 = 0; e0 < E; e0 += XU) {
+        float fx[XU];
+        load_extra(fx, rowx, N, qi, e0, E, qok);
+        for (int u = 0; u < XU && e0 + u < E; ++u)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) av16[g][k] = fmaf(Wsm[(g * R + (k < R ? k : 0)) * WST + 2 * V + 2 + e], fx, av16[g][k]);
+                for (int k = 0; k < 4; ++k) av16[g][k] = fmaf(Wsm[(g * R + (k < R ? k : 0)) * WST + 2 * V + 2 + e0 + u], fx[u], av16[g][k]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {

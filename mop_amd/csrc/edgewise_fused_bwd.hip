@@ -525,10 +525,12 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { const float *Wo = Wg4 + (k < RK ? k : 0) * WST; sk[k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, sk[k])); }
             }
-            for (int e = 0; e < E; ++e) {
-                const float fx = colx[e * N + j];
+            for (int e0 = 0; e0 < E; e0 += XU) {
+                float fx[XU];
+                load_extra(fx, colx, N, j, e0, E, true);
+                for (int u = 0; u < XU && e0 + u < E; ++u)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sk[k] = fmaf(Wg4[(k < RK ? k : 0) * WST + 2 * V + 2 + e], fx, sk[k]);
+                    for (int k = 0; k < 4; ++k) sk[k] = fmaf(Wg4[(k < RK ? k : 0) * WST + 2 * V + 2 + e0 + u], fx[u], sk[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (k < RK) { hi[k] = f2bf(sk[k]); lo[k] = f2bf(sk[k] - bf2f(hi[k])); }
@@ -561,12 +563,14 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const float *Wo = Wsm + (g * RK + (k < RK ? k : 0)) * WST; av16[g][k] = fmaf(Wo[2 * V], f0, fmaf(Wo[2 * V + 1], f1, av16[g][k])); }
     }
-    for (int e = 0; e < E; ++e) {
-        const float fx = qok ? rowx[e * N + qi] : 0.f;
+    for (int e0 = 0; e0 < E; e0 += XU) {
+        float fx[XU];
+        load_extra(fx, rowx, N, qi, e0, E, qok);
+        for (int u = 0; u < XU && e0 + u < E; ++u)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) av16[g][k] = fmaf(Wsm[(g * RK + (k < RK ? k : 0)) * WST + 2 * V + 2 + e], fx, av16[g][k]);
+                for (int k = 0; k < 4; ++k) av16[g][k] = fmaf(Wsm[(g * RK + (k < RK ? k : 0)) * WST + 2 * V + 2 + e0 + u], fx[u], av16[g][k]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -755,11 +759,14 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
         // dW partials first (they read rS/cS which dmean is about to overwrite)
         const int nO = 4 * RK;
         float *xfeat = dbv + 16 * NP;                 // [2][E][NP] extra feature rows (row side, then col side), zero padded; behind dav | dbv, below Wsm
-        if (E) {
-            for (int c = tid; c < 2 * E * NP; c += NTH) {
-                const int sd = c / (E * NP), e = (c / NP) % E, n = c % NP;
-                xfeat[c] = n < N ? (sd ? colx : rowx)[e * N + n] : 0.f;
-            }
+        if (E) {            // thread = (token n, side): XU channels requested per round trip
+            const int n = tid % NP, sd = tid / NP;
+            if (sd < 2)
+                for (int e0 = 0; e0 < E; e0 += XU) {
+                    float fx[XU];
+                    load_extra(fx, sd ? colx : rowx, N, n, e0, E, n < N);
+                    for (int u = 0; u < XU && e0 + u < E; ++u) xfeat[(sd * E + e0 + u) * NP + n] = fx[u];
+                }
             __syncthreads();
         }
         for (int idx = tid; idx < 2 * nO * (C + 1); idx += NTH) {

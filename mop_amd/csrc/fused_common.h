@@ -202,6 +202,16 @@ __host__ __device__ inline bool fa_drop_keep(const FaDrop &d, uint32_t rowh, int
 }
 
 
+// Extra feature channels (FusedDenseW::rowx / colx): XU values of one token are requested together, so a pass over E channels exposes
+// ceil(E / XU) memory round trips instead of E
+constexpr int XU = 8;
+__device__ __forceinline__ void load_extra(float (&v)[XU], const float *x, int N, int n, int e0, int E, bool ok) {
+#pragma unroll
+    for (int u = 0; u < XU; ++u) v[u] = (ok && e0 + u < E) ? x[(e0 + u) * N + n] : 0.f;
+#pragma unroll
+    for (int u = 0; u < XU; ++u) asm volatile("" : "+v"(v[u]));      // keeps the loads ahead of the first use (one wait for the batch)
+}
+
 // device pointers taken from MopkEdgewiseExt (a host struct): the dense gate head's conv1 (16, C) / (16), conv2 (4, 16) / (4); and the
 // low-rank head's E extra feature channels as their row / column means (B,H,E,N) with the gradients' destinations
 struct FusedDenseW { const float *W1, *b1, *W2, *b2; int E; const float *rowx, *colx; float *drowx, *dcolx; };

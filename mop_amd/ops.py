@@ -168,15 +168,15 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, sqk, vs0, vsL, Wr, br, Wc, bc, logit, beta_not, V, prec, path, want_bwd, drop=(0.0, 0),
-                row_extra=None, col_extra=None):
-        """row_extra / col_extra: (B,H,E,N) row / column means of E extra feature channels of the head (Wr / Wc then have
-        2V + 2 + E input channels): fused path only (MopkEdgewiseExt.n_extra)."""
+                lens_w=None, lens_dil=()):
+        """lens_w (L,V,3,3) + lens_dil: the S lens bank.  Its planes reach the head as E = L V extra feature channels given by their
+        row / column means (Wr / Wc then have 2V + 2 + E input channels): fused path only (MopkEdgewiseExt.n_extra)."""
         _require_gpu(qkv, "EdgewiseMSA")
         lib = L.lib()
         B, N, Vq, _, H, dk = qkv.shape
         qkv = qkv.contiguous()
         dev = qkv.device
-        n_extra = 0 if row_extra is None else int(row_extra.shape[2])
+        n_extra = 0 if lens_w is None else int(lens_w.shape[0] * lens_w.shape[1])
         f = dict(zip(("sqk", "vs0", "vsL", "Wr", "br", "Wc", "bc", "logit"),
                      _f32_pack([sqk, vs0, vsL, Wr, br, Wc, bc, logit.reshape(1)])))
         ctx.small_dtype = sqk.dtype if len({t.dtype for t in (sqk, vs0, vsL, Wr, br, Wc, bc, logit)}) == 1 else None
@@ -192,8 +192,11 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         y = torch.empty(B, N, H, dk, dtype=qkv.dtype, device=dev)
         a.y = L.View4(y.data_ptr(), N * H * dk, dk, H * dk)
         extras = ()
+        ctx.lens_dil, ctx.lens_dtype = tuple(lens_dil), (None if lens_w is None else lens_w.dtype)
         if n_extra:
-            extras = (_f32c(row_extra), _f32c(col_extra))
+            lens_w = _f32c(lens_w)
+            row_x, col_x, lens_state = _lens_means_fwd(qkv, f["sqk"], lens_w, lens_dil)
+            extras = (row_x.contiguous(), col_x.contiguous(), lens_w, *lens_state)
             ext = L.EdgewiseExt()
             ext.n_extra, ext.row_extra, ext.col_extra = n_extra, extras[0].data_ptr(), extras[1].data_ptr()
             a.ext = C.pointer(ext)
@@ -249,7 +252,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         n_extra = extras[0].shape[2] if extras else 0
         C_ = 2 * V + 2 + n_extra
-        d_extras = (None, None)
+        d_extras = None
         if n_extra:
             d_extras = (torch.empty_like(extras[0]), torch.empty_like(extras[1]))
             ext = L.EdgewiseExt()
@@ -276,11 +279,18 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         L.check(rc, "mopk_edgewise_lowrank_bwd")
         L.check(lib.mopk_edgewise_reduce_parts(C.byref(a), dsqk.data_ptr(), dvs0.data_ptr(), dvsL.data_ptr(), dlg.data_ptr(),
                                                _stream()), "mopk_edgewise_reduce_parts")
+        dlens = None
+        if n_extra:     # the lens means are functions of q, k, sqk and the lens weights: their gradients join the kernels' own
+            dq_x, dk_x, dsqk_x, dlens = _lens_means_bwd(d_extras[0], d_extras[1], qkv, sqk, extras[2], ctx.lens_dil, extras[3:])
+            dqkv[:, :, 0, 0].add_(dq_x.permute(0, 2, 1, 3))
+            dqkv[:, :, 0, 1].add_(dk_x.permute(0, 2, 1, 3))
+            dsqk.add_(dsqk_x.reshape(-1))
+            dlens = dlens.to(ctx.lens_dtype)
         if ctx.small_dtype is not None and ctx.small_dtype != torch.float32:
             small = small.to(ctx.small_dtype)
             dsqk, dvs0, dvsL, dWr, dbr, dWc, dbc, dlg = torch.split(small, [n_sqk, n_vs, n_vs, n_w, n_b, n_w, n_b, 1])
         return (dqkv, dsqk.view(V, H, dk), dvs0.view(H, dk), dvsL.view(H, dk), dWr.view(4 * r, C_), dbr, dWc.view(4 * r, C_), dbc,
-                dlg.reshape(()), None, None, None, None, None, None, *d_extras)
+                dlg.reshape(()), None, None, None, None, None, None, dlens, None)
 
 
 class EdgewiseVariant:
@@ -475,17 +485,102 @@ def lens_mean_features(qkv, sqk, lens_w, dilations):
     q = qkv[:, :, 0, 0].permute(0, 2, 1, 3).float()           # (B,H,N,dk)
     k = qkv[:, :, 0, 1].permute(0, 2, 1, 3).float()
     sq = sqk.float()
-    rows, cols = [], []
-    for l, d in enumerate(dilations):
-        lo = max(N - int(d), 0)                                 # |J_0| = |J_2|
-        ks = torch.stack([k[:, :, :lo].sum(2), k.sum(2), k[:, :, N - lo:].sum(2)], 2)        # (B,H,3,dk)
-        qs = torch.stack([q[:, :, :lo].sum(2), q.sum(2), q[:, :, N - lo:].sum(2)], 2)
-        w = lens_w[l].float() / N                                                           # (V,3,3) [a][b]
-        R = torch.einsum("bhid,vhd,bhsd->bhvsi", q, sq, ks).reshape(B * H, V * 3, N)
-        Cs = torch.einsum("bhjd,vhd,bhsd->bhvsj", k, sq, qs).reshape(B * H, V * 3, N)
-        rows.append(F.conv1d(R, w.permute(0, 2, 1).contiguous(), padding=int(d), dilation=int(d), groups=V).view(B, H, V, N))
-        cols.append(F.conv1d(Cs, w.contiguous(), padding=int(d), dilation=int(d), groups=V).view(B, H, V, N))
-    return torch.cat(rows, 2), torch.cat(cols, 2)
+    L_ = len(dilations)
+    dil = [int(d) for d in dilations]
+    dmax = max(dil)
+    qsum, ksum = q.sum(2), k.sum(2)
+    # sums over J_0 = all minus the last d tokens, J_1 = all, J_2 = all minus the first d (slices clamp at N: d >= N leaves nothing)
+    ks = torch.stack([torch.stack([ksum - k[:, :, max(N - d, 0):].sum(2), ksum, ksum - k[:, :, :d].sum(2)], 2) for d in dil], 2)    # (B,H,L,3,dk)
+    qs = torch.stack([torch.stack([qsum - q[:, :, max(N - d, 0):].sum(2), qsum, qsum - q[:, :, :d].sum(2)], 2) for d in dil], 2)
+    w = lens_w.float() / N                                                                  # (L,V,3,3) [a][b]
+    # the taps are folded into the (tiny) left operands first: ONE batched GEMM per side then yields, per lens, view and shift, the
+    # vector that the shift-and-add below turns into the mean
+    ua = torch.einsum("lvst,vhd,nhltd->nhlvsd", w, sq, ks).reshape(B, H, L_ * V * 3, dk)        # row side: shift index a (= s)
+    ub = torch.einsum("lvst,vhd,nhlsd->nhlvtd", w, sq, qs).reshape(B, H, L_ * V * 3, dk)        # col side: shift index b (= t)
+    Tr = F.pad(torch.matmul(ua, q.transpose(2, 3)).view(B, H, L_, V, 3, N), (dmax, dmax))      # [.., a, dmax + i]
+    Tc = F.pad(torch.matmul(ub, k.transpose(2, 3)).view(B, H, L_, V, 3, N), (dmax, dmax))
+    def shift_add(T, l, d):                                                                  # sum_a T_a[i + (a-1) d]
+        return T[:, :, l, :, 0, dmax - d:dmax - d + N] + T[:, :, l, :, 1, dmax:dmax + N] + T[:, :, l, :, 2, dmax + d:dmax + d + N]
+    return (torch.cat([shift_add(Tr, l, d) for l, d in enumerate(dil)], 2),
+            torch.cat([shift_add(Tc, l, d) for l, d in enumerate(dil)], 2))
+
+
+def _lens_set_sums(x, dil):
+    """x (B,H,N,dk) -> (B,H,L,3,dk): sums of x over the tokens J_0 = [0, N-d), J_1 = all, J_2 = [d, N) per dilation (all minus the d edge rows)"""
+    N = x.shape[2]
+    tot = x.sum(2)
+    return torch.stack([torch.stack([tot - x[:, :, N - d:].sum(2), tot, tot - x[:, :, :d].sum(2)], 2) for d in dil], 2)
+
+
+def _lens_set_sums_adjoint(dx, g, dil):
+    """dx (B,H,N,dk) += adjoint of _lens_set_sums applied to g (B,H,L,3,dk), in place"""
+    N = dx.shape[2]
+    dx += g.sum((2, 3))[:, :, None, :]
+    for l, d in enumerate(dil):
+        dx[:, :, N - d:] -= g[:, :, l, 0][:, :, None, :]
+        dx[:, :, :d] -= g[:, :, l, 2][:, :, None, :]
+    return dx
+
+
+def _lens_shift_add(T, dil, dmax, N):
+    """T (B,H,L,V,3,N + 2 dmax), zero padded by dmax: -> (B,H,L*V,N)  sum_a T[l,v,a][i + (a-1) d_l]"""
+    return torch.cat([T[:, :, l, :, 0, dmax - d:dmax - d + N] + T[:, :, l, :, 1, dmax:dmax + N] + T[:, :, l, :, 2, dmax + d:dmax + d + N]
+                      for l, d in enumerate(dil)], 2)
+
+
+def _lens_unshift(dM, dil, dmax, N, V):
+    """adjoint of _lens_shift_add: dM (B,H,L*V,N) -> (B,H,L*V*3,N)  dT[l,v,a][i'] = dM[l,v][i' - (a-1) d_l] (0 outside)"""
+    B, H = dM.shape[:2]
+    P = F.pad(dM.view(B, H, len(dil), V, N), (dmax, dmax))
+    return torch.stack([torch.stack([P[:, :, l, :, dmax + d:dmax + d + N], P[:, :, l, :, dmax:dmax + N], P[:, :, l, :, dmax - d:dmax - d + N]], 3)
+                        for l, d in enumerate(dil)], 2).reshape(B, H, -1, N)
+
+
+def _lens_means_fwd(qkv, sqk, lens_w, dilations):
+    """`lens_mean_features` without an autograd graph (for use inside a Function): -> row, col (B,H,L*V,N), state for `_lens_means_bwd`.
+    (No graph: under autograd every slice of the (B,H,N,dk) tensors costs a full-size zero-fill + add in the backward.)"""
+    B, N, _, _, H, dk = qkv.shape
+    V, L_ = sqk.shape[0], len(dilations)
+    dil = [min(int(d), N) for d in dilations]
+    dmax = max(dil)
+    q = qkv[:, :, 0, 0].permute(0, 2, 1, 3).float()
+    k = qkv[:, :, 0, 1].permute(0, 2, 1, 3).float()
+    ks, qs = _lens_set_sums(k, dil), _lens_set_sums(q, dil)
+    w = lens_w.float() / N
+    ua = torch.einsum("lvst,vhd,nhltd->nhlvsd", w, sqk, ks).reshape(B, H, L_ * V * 3, dk)
+    ub = torch.einsum("lvst,vhd,nhlsd->nhlvtd", w, sqk, qs).reshape(B, H, L_ * V * 3, dk)
+    Tr = F.pad(torch.matmul(ua, q.transpose(2, 3)).view(B, H, L_, V, 3, N), (dmax, dmax))
+    Tc = F.pad(torch.matmul(ub, k.transpose(2, 3)).view(B, H, L_, V, 3, N), (dmax, dmax))
+    return _lens_shift_add(Tr, dil, dmax, N), _lens_shift_add(Tc, dil, dmax, N), (ks, qs, ua, ub)
+
+
+def _lens_means_bwd(d_row, d_col, qkv, sqk, lens_w, dilations, state):
+    """-> dq, dk (B,H,N,dk) float32, dsqk (V,H,dk), dlens_w (L,V,3,3)"""
+    B, N, _, _, H, dk = qkv.shape
+    V, L_ = sqk.shape[0], len(dilations)
+    dil = [min(int(d), N) for d in dilations]
+    dmax = max(dil)
+    ks, qs, ua, ub = state
+    q = qkv[:, :, 0, 0].permute(0, 2, 1, 3).float()
+    k = qkv[:, :, 0, 1].permute(0, 2, 1, 3).float()
+    w = lens_w.float() / N
+    dTr, dTc = _lens_unshift(d_row, dil, dmax, N, V), _lens_unshift(d_col, dil, dmax, N, V)       # (B,H,L*V*3,N)
+    dua = torch.matmul(dTr, q).view(B, H, L_, V, 3, dk)
+    dub = torch.matmul(dTc, k).view(B, H, L_, V, 3, dk)
+    dq = torch.matmul(dTr.transpose(2, 3), ua)
+    dk_ = torch.matmul(dTc.transpose(2, 3), ub)
+    # through ua = w . sqk . ks and ub = w . sqk . qs
+    gs_a, gs_b = dua * sqk.permute(1, 0, 2)[None, :, None, :, None, :], dub * sqk.permute(1, 0, 2)[None, :, None, :, None, :]   # (B,H,L,V,3,dk)
+    # contractions over (batch, head, d) with a 3 x 3 result per (l, v): a broadcast product + one reduction (as a GEMM they are
+    # K = B H dk deep with a 30 x 3 output -- one workgroup's worth of parallelism)
+    dw = ((gs_a[:, :, :, :, :, None, :] * ks[:, :, :, None, None, :, :]).sum((0, 1, 6)) +
+          (gs_b[:, :, :, :, None, :, :] * qs[:, :, :, None, :, None, :]).sum((0, 1, 6))) / N
+    wks = torch.einsum("lvst,nhltd->nhlvsd", w, ks)
+    wqs = torch.einsum("lvst,nhlsd->nhlvtd", w, qs)
+    dsqk = (dua * wks + dub * wqs).sum((0, 2, 4)).permute(1, 0, 2)                               # (V,H,dk)
+    dks = torch.einsum("nhlvsd,lvst->nhltd", gs_a, w).reshape(B, H, L_ * 3, dk)
+    dqs = torch.einsum("nhlvtd,lvst->nhlsd", gs_b, w).reshape(B, H, L_ * 3, dk)
+    return _lens_set_sums_adjoint(dq, dqs.view(B, H, L_, 3, dk), dil), _lens_set_sums_adjoint(dk_, dks.view(B, H, L_, 3, dk), dil), dsqk, dw
 
 
 def lowrank_lens_fused_supported(qkv, n_views: int, rank: int, n_lens: int, precision: Optional[int] = None) -> bool:
@@ -510,16 +605,16 @@ def edgewise_lowrank_core(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_
                           dropout_p: float = 0.0, seed: Optional[int] = None, lens_w=None, lens_dilations=()):
     """qkv: (B,N,Vq,3,H,dk) with Vq in {1 (share_qkv), n_views}; returns (B,N,H*dk).  dropout_p > 0: attn_drop on the mixed
     attention weights (:552) inside the fused kernels (see `sdpa_core`).  lens_w (L,V,3,3) + lens_dilations: the S lens bank, fed to
-    the fused kernels as extra mean-feature channels (`lens_mean_features`; callers check `lowrank_lens_fused_supported` first)."""
+    the fused kernels as extra mean-feature channels (`lens_mean_features` states the closed form; the Function evaluates it and its
+    backward by hand, `_lens_means_fwd` / `_lens_means_bwd`; callers check `lowrank_lens_fused_supported` first)."""
     if qkv.shape[0] == 0:
         return _empty_batch(qkv, 0, qkv.shape[1], qkv.shape[-2] * qkv.shape[-1])
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     prec = _prec_for(qkv.dtype) if precision is None else precision
     want_bwd = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, lens_w))
-    extras = (None, None) if lens_w is None else lens_mean_features(qkv, sqk, lens_w, lens_dilations)
     return _EdgewiseLowrankFn.apply(qkv, sqk, vs0, vsL, Wr, br, Wc, bc, chain_logit, beta_not,
-                                    n_views, prec, _PATH if path is None else path, want_bwd, drop, *extras)
+                                    n_views, prec, _PATH if path is None else path, want_bwd, drop, lens_w, tuple(lens_dilations))
 
 
 # --------------------------------------------------------------------------------------

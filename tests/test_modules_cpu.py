@@ -257,3 +257,37 @@ def test_vit_mop_state_dict_matches_the_reference_layout(name):
     ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     assert list(ours.items()) == list(shapes.items())
     assert sum(p.numel() for p in m.parameters()) == int(meta["n_params"])
+
+
+@pytest.mark.parametrize("shape", [(2, 13, 3, 8, 4, (1, 2)), (1, 5, 2, 4, 3, (1, 7, 5)), (2, 33, 2, 16, 2, (3,)), (1, 4, 1, 4, 2, (4, 2))])
+def test_lens_mean_features_closed_form(shape):
+    """S lens bank row / column means (reference attention_variants.py:523-533 followed by the head's means :323-326) in closed form:
+    ops.lens_mean_features against the planes convolved with F.conv2d, and the hand-written forward / backward the fused route uses
+    (ops._lens_means_fwd / _lens_means_bwd) against autograd of the same."""
+    import torch.nn.functional as F
+    from mop_amd import ops
+    B, N, H, dk, V, dil = shape
+    torch.manual_seed(N)
+    qkv = torch.randn(B, N, 1, 3, H, dk, dtype=torch.float64, requires_grad=True)
+    sqk = torch.randn(V, H, dk, dtype=torch.float64, requires_grad=True)
+    lw = torch.randn(len(dil), V, 3, 3, dtype=torch.float64, requires_grad=True)
+    q, k = qkv[:, :, 0, 0].permute(0, 2, 1, 3), qkv[:, :, 0, 1].permute(0, 2, 1, 3)
+    S = torch.einsum("bhid,vhd,bhjd->bhvij", q, sqk, k).reshape(B * H, V, N, N)
+    planes = [F.conv2d(S, lw[l][:, None], padding=d, dilation=d, groups=V) for l, d in enumerate(dil)]
+    r0 = torch.cat([o.mean(3).view(B, H, V, N) for o in planes], 2)
+    c0 = torch.cat([o.mean(2).view(B, H, V, N) for o in planes], 2)
+    gr, gc = torch.randn_like(r0), torch.randn_like(c0)
+    g0 = torch.autograd.grad((r0 * gr).sum() + (c0 * gc).sum(), (qkv, sqk, lw))
+    orig_float = torch.Tensor.float
+    torch.Tensor.float = lambda t: t.double()            # keep the check in float64 (the product code computes in float32)
+    try:
+        r1, c1 = ops.lens_mean_features(qkv, sqk, lw, dil)
+        r2, c2, st = ops._lens_means_fwd(qkv.detach(), sqk.detach(), lw.detach(), dil)
+        dq, dk_, dsqk, dlw = ops._lens_means_bwd(gr, gc, qkv.detach(), sqk.detach(), lw.detach(), dil, st)
+    finally:
+        torch.Tensor.float = orig_float
+    for a_, b_ in ((r1, r0), (c1, c0), (r2, r0), (c2, c0)):
+        assert float((a_ - b_).detach().abs().max()) <= 1e-10 * max(1.0, float(b_.detach().abs().max()))
+    assert float((dq.permute(0, 2, 1, 3) - g0[0][:, :, 0, 0]).abs().max()) <= 1e-9
+    assert float((dk_.permute(0, 2, 1, 3) - g0[0][:, :, 0, 1]).abs().max()) <= 1e-9
+    assert float((dsqk - g0[1]).abs().max()) <= 1e-9 and float((dlw - g0[2]).abs().max()) <= 1e-9
