@@ -17,7 +17,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 st = struct.unpack("32Q", ops.LAST_PATH["_fwd_ws"][:256].cpu().numpy().tobytes())
 names = ["P0 stage + means", "row constants", "chain <-", "chain -> (+exports, V^T, y_chain)", "gate vectors", "mix", "softmax + P V0"]
-vals = [s for s in st if s]
+vals = list(st[:len(names) + 1])            # the kernel writes one stamp per phase boundary; the rest of the buffer is uninitialised
 tot = vals[-1] - vals[0]
 for i in range(len(vals) - 1):
     print(f"{(names[i] if i < len(names) else str(i)):36s} {vals[i+1]-vals[i]:10d} cyc  {100.0*(vals[i+1]-vals[i])/tot:5.1f}%")
