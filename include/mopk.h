@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 116 /* 116: MopkEdgewiseExt.{n_extra,row_extra,col_extra,d_row_extra,d_col_extra}; 115: mask tensors on the fused dual-path kernels; 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
+#define MOPK_VERSION 117 /* 117: mopk_lens_means_{fwd,bwd}; 116: MopkEdgewiseExt.{n_extra,row_extra,col_extra,d_row_extra,d_col_extra}; 115: mask tensors on the fused dual-path kernels; 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -341,6 +341,32 @@ typedef struct MopkLayerNormArgs {
 size_t mopk_layernorm_workspace_bytes(const MopkLayerNormArgs *a);
 int mopk_layernorm_fwd(const MopkLayerNormArgs *a, void *stream);
 int mopk_layernorm_bwd(const MopkLayerNormArgs *a, void *stream);
+
+/* --------------------------------------------------------------------------
+ * Row / column means of the S lens bank's planes in closed form -- the values MopkEdgewiseExt.row_extra / col_extra take.
+ * The bank (attention_variants.py:425-442, :523-533) convolves every score plane S_v = (q * sqk_v) k^T with a depthwise dilated
+ * 3x3 kernel (zero padding = dilation); the low-rank head reads only row / column means of the result (:323-326), which are
+ * linear functionals of q and k (O(N dk) per (b, h, view); see mop_amd/csrc/lens_means.hip).  N <= 224, dk in {16, 32, 64},
+ * L * V <= 16, and a working set (grows with the largest dilation) within the CU's 160 KB of LDS: mopk_lens_means_supported.  q / k: the shared (sv == 0) queries / keys of the Edgewise call.
+ *   _fwd: row, col (B,H,L*V,N) fp32, channel l * V + v (the reference's order, :531).
+ *   _bwd: given d_row / d_col, ADDS the q / k gradients into dq / dk_ (the buffers the Edgewise backward has already written,
+ *         io_dtype elements) and writes per-(b) / per-(b,h) partials of the scale and weight gradients for the caller to sum:
+ *         dsqk_part (B,V,H,dk), dlens_part (B*H,L,V,3,3). */
+typedef struct MopkLensMeansArgs {
+    int32_t B, H, N, dk, V, L;
+    int32_t io_dtype;              /* MopkDtype of q, k, dq, dk_ */
+    int32_t dil[MOPK_MAX_LENS];    /* dilation == padding of each lens   :430-436 */
+    MopkView4 q, k;
+    const float *sqk;              /* (V,H,dk) fp32, as MopkEdgewiseArgs.sqk */
+    const float *lens_w;           /* (L,V,3,3) fp32: lens_bank[l].weight[:, 0] */
+    float *row, *col;              /* fwd out */
+    const float *d_row, *d_col;    /* bwd in  */
+    MopkView4 dq, dk_;             /* bwd in/out: += */
+    float *dsqk_part, *dlens_part; /* bwd out */
+} MopkLensMeansArgs;
+int mopk_lens_means_supported(const MopkLensMeansArgs *a, int backward);   /* 1 if the kernels take this shape (dimensions and dil only) */
+int mopk_lens_means_fwd(const MopkLensMeansArgs *a, void *stream);
+int mopk_lens_means_bwd(const MopkLensMeansArgs *a, void *stream);
 
 /* -------------------------------------------------------------------------- */
 int mopk_version(void);

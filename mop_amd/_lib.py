@@ -123,6 +123,15 @@ class LayerNormArgs(C.Structure):
     ]
 
 
+class LensMeansArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("H", C.c_int32), ("N", C.c_int32), ("dk", C.c_int32), ("V", C.c_int32), ("L", C.c_int32),
+        ("io_dtype", C.c_int32), ("dil", C.c_int32 * MAX_LENS),
+        ("q", View4), ("k", View4), ("sqk", _fp), ("lens_w", _fp), ("row", _fp), ("col", _fp), ("d_row", _fp), ("d_col", _fp),
+        ("dq", View4), ("dk_", View4), ("dsqk_part", _fp), ("dlens_part", _fp),
+    ]
+
+
 SYMBOLS = {
     "mopk_version": (C.c_int, []),
     "mopk_strerror": (C.c_char_p, [C.c_int]),
@@ -157,6 +166,9 @@ SYMBOLS = {
     "mopk_dropout_keep": (C.c_int, [C.c_uint64, C.c_float, C.c_int64, C.c_int64, C.c_int64]),
     "mopk_layernorm_workspace_bytes": (C.c_size_t, [C.POINTER(LayerNormArgs)]),
     "mopk_layernorm_fwd": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
+    "mopk_lens_means_supported": (C.c_int, [C.POINTER(LensMeansArgs), C.c_int]),
+    "mopk_lens_means_fwd": (C.c_int, [C.POINTER(LensMeansArgs), C.c_void_p]),
+    "mopk_lens_means_bwd": (C.c_int, [C.POINTER(LensMeansArgs), C.c_void_p]),
     "mopk_layernorm_bwd": (C.c_int, [C.POINTER(LayerNormArgs), C.c_void_p]),
 }
 

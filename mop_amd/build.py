@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libmopk.so")
-PLAIN = ["api.hip", "edgewise_generic.hip", "attn_generic.hip", "sdpa_flash.hip", "quartet_flash.hip", "layernorm.hip"]
+PLAIN = ["api.hip", "edgewise_generic.hip", "attn_generic.hip", "sdpa_flash.hip", "quartet_flash.hip", "layernorm.hip", "lens_means.hip"]
 FUSED = ["edgewise_fused.hip", "edgewise_fused_bwd.hip"]
 FUSED_INST_ONLY = []      # files compiled per (NT, DK) only (entry points called from the files above)
 NTS, DKS = (1, 2, 3, 4, 5, 6, 7), (16, 32, 64)      # NT = 3: N <= 96 (the reference's CIFAR sequence length, N = 65)

@@ -28,6 +28,8 @@ int qt_flash_fwd(const MopkQuartetArgs *a, hipStream_t st); int qt_flash_bwd(con
 size_t cv_saved_bytes(const MopkCrossViewArgs *a); size_t cv_ws_bytes(const MopkCrossViewArgs *a);
 int cv_fwd(const MopkCrossViewArgs *a, hipStream_t st); int cv_bwd(const MopkCrossViewArgs *a, hipStream_t st);
 int qt_fwd(const MopkQuartetArgs *a, hipStream_t st); int qt_bwd(const MopkQuartetArgs *a, hipStream_t st);
+int lens_means_run(const MopkLensMeansArgs *a, bool bwd, hipStream_t st);
+int lens_means_supported(const MopkLensMeansArgs *a, bool bwd);
 
 static int ew_validate(const MopkEdgewiseArgs *a, bool bwd) {
     if (!a) return MOPK_ERR_BAD_ARG;
@@ -120,6 +122,9 @@ int mopk_edgewise_bwd(const MopkEdgewiseArgs *a, void *stream) {
     if (a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;
     return ew_generic_bwd(a, (hipStream_t)stream);
 }
+int mopk_lens_means_supported(const MopkLensMeansArgs *a, int backward) { return lens_means_supported(a, backward != 0); }
+int mopk_lens_means_fwd(const MopkLensMeansArgs *a, void *stream) { return lens_means_run(a, false, (hipStream_t)stream); }
+int mopk_lens_means_bwd(const MopkLensMeansArgs *a, void *stream) { return lens_means_run(a, true, (hipStream_t)stream); }
 int mopk_edgewise_lowrank_fwd(const MopkEdgewiseArgs *a, void *stream) {
     if (a && a->ext && a->ext->gate_mode != 0) return MOPK_ERR_BAD_ARG;
     return mopk_edgewise_fwd(a, stream);

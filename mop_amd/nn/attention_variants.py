@@ -235,7 +235,7 @@ class EdgewiseMSA(nn.Module):
         # low-rank head + S lens bank: the head reads row / column means only, and those of the lens planes have a closed form in q, k
         # (ops.lens_mean_features) -- the fused kernels take them as extra feature channels, no N x N plane is ever convolved
         lens_fused = (not dense and self.use_lens_bank and attn_mask is None and qkv.shape[2] == 1 and
-                      ops.lowrank_lens_fused_supported(qkv, n_s, eh.row_proj.weight.shape[0] // 4, len(self.lens_dilations)))
+                      ops.lowrank_lens_fused_supported(qkv, n_s, eh.row_proj.weight.shape[0] // 4, self.lens_dilations))
         if not dense and attn_mask is None and (lens_fused or not self.use_lens_bank):
             lens_w = torch.stack([c.weight[:, 0] for c in self.lens_bank]) if lens_fused else None           # (L,V,3,3)
             y = ops.edgewise_lowrank_core(qkv, sqk, vs0, vsL, eh.row_proj.weight.squeeze(-1), eh.row_proj.bias,

@@ -195,8 +195,8 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         ctx.lens_dil, ctx.lens_dtype = tuple(lens_dil), (None if lens_w is None else lens_w.dtype)
         if n_extra:
             lens_w = _f32c(lens_w)
-            row_x, col_x, lens_state = _lens_means_fwd(qkv, f["sqk"], lens_w, lens_dil)
-            extras = (row_x.contiguous(), col_x.contiguous(), lens_w, *lens_state)
+            row_x, col_x = lens_means_hip(qkv, f["sqk"], lens_w, lens_dil)
+            extras = (row_x, col_x, lens_w)
             ext = L.EdgewiseExt()
             ext.n_extra, ext.row_extra, ext.col_extra = n_extra, extras[0].data_ptr(), extras[1].data_ptr()
             a.ext = C.pointer(ext)
@@ -281,9 +281,7 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
                                                _stream()), "mopk_edgewise_reduce_parts")
         dlens = None
         if n_extra:     # the lens means are functions of q, k, sqk and the lens weights: their gradients join the kernels' own
-            dq_x, dk_x, dsqk_x, dlens = _lens_means_bwd(d_extras[0], d_extras[1], qkv, sqk, extras[2], ctx.lens_dil, extras[3:])
-            dqkv[:, :, 0, 0].add_(dq_x.permute(0, 2, 1, 3))
-            dqkv[:, :, 0, 1].add_(dk_x.permute(0, 2, 1, 3))
+            dsqk_x, dlens = lens_means_bwd_hip(d_extras[0], d_extras[1], qkv, dqkv, sqk, extras[2], ctx.lens_dil)
             dsqk.add_(dsqk_x.reshape(-1))
             dlens = dlens.to(ctx.lens_dtype)
         if ctx.small_dtype is not None and ctx.small_dtype != torch.float32:
@@ -536,9 +534,51 @@ def _lens_unshift(dM, dil, dmax, N, V):
                         for l, d in enumerate(dil)], 2).reshape(B, H, -1, N)
 
 
+def _lens_args(qkv, sqk, lens_w, dilations) -> L.LensMeansArgs:
+    B, N, _, _, H, dk = qkv.shape
+    a = L.LensMeansArgs()
+    a.B, a.H, a.N, a.dk, a.V, a.L = B, H, N, dk, sqk.shape[0], len(dilations)
+    a.io_dtype = _io_dtype(qkv)
+    for i, d in enumerate(dilations):
+        a.dil[i] = int(d)
+    s_n = 3 * H * dk
+    a.q = L.View4(qkv.data_ptr(), N * s_n, dk, s_n)
+    a.k = L.View4(qkv.data_ptr() + H * dk * qkv.element_size(), N * s_n, dk, s_n)
+    a.sqk, a.lens_w = sqk.data_ptr(), lens_w.data_ptr()
+    return a
+
+
+def lens_means_hip(qkv, sqk, lens_w, dilations):
+    """row / col means of the S lens bank's planes (B,H,L*V,N) fp32 from libmopk's closed-form kernel (mopk_lens_means_fwd);
+    qkv (B,N,1,3,H,dk) contiguous on the GPU, sqk (V,H,dk) / lens_w (L,V,3,3) float32 contiguous."""
+    _require_gpu(qkv, "lens means")
+    B, N, _, _, H, dk = qkv.shape
+    E = lens_w.shape[0] * lens_w.shape[1]
+    a = _lens_args(qkv, sqk, lens_w, dilations)
+    row, col = torch.empty(B, H, E, N, dtype=torch.float32, device=qkv.device), torch.empty(B, H, E, N, dtype=torch.float32, device=qkv.device)
+    a.row, a.col = row.data_ptr(), col.data_ptr()
+    L.check(L.lib().mopk_lens_means_fwd(C.byref(a), _stream()), "mopk_lens_means_fwd")
+    return row, col
+
+
+def lens_means_bwd_hip(d_row, d_col, qkv, dqkv, sqk, lens_w, dilations):
+    """backward of `lens_means_hip`: ADDS the q / k gradients into dqkv (same layout as qkv) and returns dsqk (V,H,dk), dlens_w (L,V,3,3)"""
+    B, N, _, _, H, dk = qkv.shape
+    V, Ln = sqk.shape[0], lens_w.shape[0]
+    a = _lens_args(qkv, sqk, lens_w, dilations)
+    s_n = 3 * H * dk
+    a.dq = L.View4(dqkv.data_ptr(), N * s_n, dk, s_n)
+    a.dk_ = L.View4(dqkv.data_ptr() + H * dk * dqkv.element_size(), N * s_n, dk, s_n)
+    dsqk_p = torch.empty(B, V, H, dk, dtype=torch.float32, device=qkv.device)
+    dlens_p = torch.empty(B * H, Ln, V, 3, 3, dtype=torch.float32, device=qkv.device)
+    a.d_row, a.d_col, a.dsqk_part, a.dlens_part = d_row.data_ptr(), d_col.data_ptr(), dsqk_p.data_ptr(), dlens_p.data_ptr()
+    L.check(L.lib().mopk_lens_means_bwd(C.byref(a), _stream()), "mopk_lens_means_bwd")
+    return dsqk_p.sum(0), dlens_p.sum(0)
+
+
 def _lens_means_fwd(qkv, sqk, lens_w, dilations):
-    """`lens_mean_features` without an autograd graph (for use inside a Function): -> row, col (B,H,L*V,N), state for `_lens_means_bwd`.
-    (No graph: under autograd every slice of the (B,H,N,dk) tensors costs a full-size zero-fill + add in the backward.)"""
+    """`lens_mean_features` without an autograd graph, in torch ops: -> row, col (B,H,L*V,N), state for `_lens_means_bwd`.  The statement
+    the HIP kernels (`lens_means_hip`, mop_amd/csrc/lens_means.hip) are tested against; the product path calls the kernels."""
     B, N, _, _, H, dk = qkv.shape
     V, L_ = sqk.shape[0], len(dilations)
     dil = [min(int(d), N) for d in dilations]
@@ -583,11 +623,21 @@ def _lens_means_bwd(d_row, d_col, qkv, sqk, lens_w, dilations, state):
     return _lens_set_sums_adjoint(dq, dqs.view(B, H, L_, 3, dk), dil), _lens_set_sums_adjoint(dk_, dks.view(B, H, L_, 3, dk), dil), dsqk, dw
 
 
-def lowrank_lens_fused_supported(qkv, n_views: int, rank: int, n_lens: int, precision: Optional[int] = None) -> bool:
-    """True when the fused kernels take this low-rank call with an S lens bank of n_lens dilations (as extra mean-feature channels)"""
+def lowrank_lens_fused_supported(qkv, n_views: int, rank: int, dilations, precision: Optional[int] = None) -> bool:
+    """True when the fused kernels take this low-rank call with an S lens bank of these dilations (as extra mean-feature channels) and
+    libmopk's closed-form kernels (mopk_lens_means_*) take the bank"""
+    n_lens = len(dilations)
     if not qkv.is_cuda or qkv.shape[2] != 1 or qkv.shape[0] == 0 or _PATH == L.PATH_GENERIC or qkv.dtype == torch.float16:
         return False
+    if not 1 <= n_lens <= L.MAX_LENS:
+        return False
     B, N, _, _, H, dk = qkv.shape
+    lm = L.LensMeansArgs()
+    lm.B, lm.H, lm.N, lm.dk, lm.V, lm.L = B, H, N, dk, n_views, n_lens
+    for i, d in enumerate(dilations):
+        lm.dil[i] = int(d)
+    if not L.lib().mopk_lens_means_supported(C.byref(lm), 1):
+        return False
     a, ext = L.EdgewiseArgs(), L.EdgewiseExt()
     a.B, a.H, a.N, a.dk, a.V, a.r = B, H, N, dk, n_views, rank
     a.io_dtype, a.path = _io_dtype(qkv), L.PATH_FUSED

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.mopk_version() == 116
+    assert lib.mopk_version() == 117
     assert lib.mopk_strerror(0) == b"ok"
     assert b"shape" in lib.mopk_strerror(-1)
 
@@ -43,9 +43,9 @@ def test_struct_sizes_match_header(lib):
     prog = r'''
 #include <stdio.h>
 #include "mopk.h"
-int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(MopkView4), sizeof(MopkView5),
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(MopkView4), sizeof(MopkView5),
  sizeof(MopkEdgewiseArgs), sizeof(MopkDualPathArgs), sizeof(MopkQuartetArgs), sizeof(MopkSdpaArgs), sizeof(MopkEdgewiseExt),
- sizeof(MopkCrossViewArgs), sizeof(MopkLayerNormArgs));return 0;}
+ sizeof(MopkCrossViewArgs), sizeof(MopkLayerNormArgs), sizeof(MopkLensMeansArgs));return 0;}
 '''
     with tempfile.TemporaryDirectory() as td:
         cpath = os.path.join(td, "s.c")
@@ -55,7 +55,8 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(MopkView4)
         sizes = list(map(int, subprocess.check_output([exe]).split()))
     from mop_amd import _lib
     mine = [C.sizeof(t) for t in (_lib.View4, _lib.View5, _lib.EdgewiseArgs, _lib.DualPathArgs,
-                                  _lib.QuartetArgs, _lib.SdpaArgs, _lib.EdgewiseExt, _lib.CrossViewArgs, _lib.LayerNormArgs)]
+                                  _lib.QuartetArgs, _lib.SdpaArgs, _lib.EdgewiseExt, _lib.CrossViewArgs, _lib.LayerNormArgs,
+                                  _lib.LensMeansArgs)]
     assert mine == sizes
 
 

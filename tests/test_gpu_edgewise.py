@@ -511,6 +511,39 @@ def test_fused_lowrank_lens_bank_vs_oracle_and_generic(shape):
         assert e <= max(GTOL_BF16, 2.0 * eg), f"{k}: fused {e:.3e} generic {eg:.3e}"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 197, 6, 64, 5, (1, 2)), (3, 50, 2, 32, 3, (1, 2, 3)), (1, 8, 4, 16, 2, (1, 9)), (1, 224, 1, 64, 4, (2, 7, 1, 10)), (1, 100, 1, 32, 2, (150, 60)),
+                                   (2, 1, 2, 64, 2, (1,))])
+def test_lens_means_kernels_vs_torch_statement(shape, dtype):
+    """mopk_lens_means_fwd / _bwd (mop_amd/csrc/lens_means.hip) against the torch statement of the same closed form (ops._lens_means_fwd /
+    _lens_means_bwd, itself pinned against F.conv2d planes and autograd on the CPU): means, q / k gradients (added into an existing
+    buffer), scale and lens-weight gradients."""
+    from mop_amd import ops
+    B, N, H, dk, V, dil = shape
+    torch.manual_seed(N + V)
+    qkv = torch.randn(B, N, 1, 3, H, dk, device="cuda").to(dtype)
+    sqk = (0.125 + 0.05 * torch.randn(V, H, dk, device="cuda")).contiguous()
+    lw = torch.randn(len(dil), V, 3, 3, device="cuda").contiguous()
+    qb = qkv.to(torch.bfloat16).float()                      # the kernel works on bf16-rounded q / k, like the fused Edgewise kernels
+    r0, c0, st = ops._lens_means_fwd(qb, sqk, lw, dil)
+    r1, c1 = ops.lens_means_hip(qkv, sqk, lw, dil)
+    scale = float(r0.abs().max()) + 1e-6
+    assert float((r1 - r0).abs().max()) <= 2e-5 * scale and float((c1 - c0).abs().max()) <= 2e-5 * (float(c0.abs().max()) + 1e-6)
+    gr, gc = torch.randn_like(r0), torch.randn_like(c0)
+    dq0, dk0, dsqk0, dlw0 = ops._lens_means_bwd(gr, gc, qb, sqk, lw, dil, st)
+    base = torch.randn_like(qkv)
+    dqkv = base.clone()
+    dsqk1, dlw1 = ops.lens_means_bwd_hip(gr, gc, qkv, dqkv, sqk, lw, dil)
+    exp = base.float().clone()
+    exp[:, :, 0, 0] += dq0.permute(0, 2, 1, 3)
+    exp[:, :, 0, 1] += dk0.permute(0, 2, 1, 3)
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-5            # bf16 buffer: one rounding of the sum
+    assert float((dqkv.float() - exp).abs().max()) <= tol * (float(exp.abs().max()) + 1e-6)
+    assert torch.equal(dqkv[:, :, 0, 2], base[:, :, 0, 2])     # v is not touched
+    assert float((dsqk1 - dsqk0).abs().max()) <= 1e-4 * (float(dsqk0.abs().max()) + 1e-6)
+    assert float((dlw1 - dlw0).abs().max()) <= 1e-4 * (float(dlw0.abs().max()) + 1e-6)
+
+
 def test_fused_lowrank_lens_bank_takes_dropout():
     """attn_drop in training mode with the S lens bank: carried by the fused kernels (the generic path would refuse)"""
     import mop_amd
