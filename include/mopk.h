@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOPK_VERSION 117 /* 117: mopk_lens_means_{fwd,bwd}; 116: MopkEdgewiseExt.{n_extra,row_extra,col_extra,d_row_extra,d_col_extra}; 115: mask tensors on the fused dual-path kernels; 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
+#define MOPK_VERSION 118 /* 118: attention dropout on every generic path, MopkCrossViewArgs.{dropout_p,dropout_seed}; 117: mopk_lens_means_{fwd,bwd}; 116: MopkEdgewiseExt.{n_extra,row_extra,col_extra,d_row_extra,d_col_extra}; 115: mask tensors on the fused dual-path kernels; 114: MopkEdgewiseArgs.mask (generic path), fused dense gate head; 113: attention dropout in the fused SDPA / Quartet kernels (dropout_p, dropout_seed, mopk_dropout_keep); 112: mopk_layernorm_*; 0.1.1: MopkEdgewiseArgs.{save_for_backward, ext}, MopkCrossViewArgs, *_fused_supported, y read by the sibling _bwd; 111: mopk_edgewise_reduce_parts */
 
 typedef enum MopkStatus {
     MOPK_OK = 0,
@@ -149,7 +149,7 @@ typedef struct MopkEdgewiseArgs {
     float *dlogit_part;      /* out: (B,H) */
 
     const MopkEdgewiseExt *ext; /* host pointer; NULL = low-rank head without lens bank (the only form the fused path takes) */
-    float dropout_p;         /* attn_drop on the mixed attention weights (:552), fused path only; see MopkSdpaArgs.dropout_p */
+    float dropout_p;         /* attn_drop on the mixed attention weights (:552); see MopkSdpaArgs.dropout_p */
     uint64_t dropout_seed;
     /* Optional attention mask, 1 = keep (generic path only).  EXTENSION: the reference's masked EdgewiseMSA is NaN for any blocking
      * mask (-inf scores enter the feature stack, :504-506 -> :518-546).  Here the mask acts on the probabilities only -- the per-view
@@ -257,8 +257,8 @@ typedef struct MopkSdpaArgs {
     MopkView4 dy, dq, dk_, dv;
     /* attention dropout (`self.attn_drop(A)` components.py:62, attention_variants.py:45, `self.attn_dropout` quartet_attn_patch.py:119):
      * probabilities are multiplied by keep(b,h,i,j) / (1 - dropout_p) after the softmax, keep = mopk_dropout_keep(); the same
-     * function is evaluated again in _bwd (nothing is stored), so pass the same p and seed to both.  0 = off.  Fused path only:
-     * the generic path returns MOPK_ERR_UNSUPPORTED when dropout_p > 0. */
+     * function is evaluated again in _bwd (nothing is stored), so pass the same p and seed to both.  0 = off.  Both paths draw the
+     * same mask from a seed (the generic path multiplies its N x N map by it in a workspace plane). */
     float dropout_p;
     uint64_t dropout_seed;
 } MopkSdpaArgs;
@@ -299,6 +299,8 @@ typedef struct MopkCrossViewArgs {
     /* backward */
     MopkView4 dy, dq1, dk1, dv1, dq2, dk2;
     float *dmix_part;        /* (B,H,4) */
+    float dropout_p;         /* attn_drop on the final attention weights (:151), see MopkSdpaArgs.dropout_p */
+    uint64_t dropout_seed;
 } MopkCrossViewArgs;
 
 size_t mopk_crossview_saved_bytes(const MopkCrossViewArgs *a);

@@ -110,7 +110,7 @@ class CrossViewArgs(C.Structure):
         ("mix", _fp), ("mask", _fp), ("mask_sb", C.c_int64), ("mask_sh", C.c_int64), ("mask_si", C.c_int64),
         ("y", View4), ("saved", _fp), ("workspace", _fp), ("k_star", _fp),
         ("dy", View4), ("dq1", View4), ("dk1", View4), ("dv1", View4), ("dq2", View4), ("dk2", View4),
-        ("dmix_part", _fp),
+        ("dmix_part", _fp), ("dropout_p", C.c_float), ("dropout_seed", C.c_uint64),
     ]
 
 

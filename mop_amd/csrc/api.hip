@@ -112,14 +112,12 @@ int mopk_edgewise_fwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, false);
     if (rc) return rc;
     if (a->path == MOPK_PATH_FUSED) return ew_fused_fwd(a, (hipStream_t)stream);
-    if (a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;          // attention dropout lives in the fused kernels only
     return ew_generic_fwd(a, (hipStream_t)stream);
 }
 int mopk_edgewise_bwd(const MopkEdgewiseArgs *a, void *stream) {
     int rc = ew_validate(a, true);
     if (rc) return rc;
     if (a->path == MOPK_PATH_FUSED) return ew_fused_bwd(a, (hipStream_t)stream);
-    if (a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;
     return ew_generic_bwd(a, (hipStream_t)stream);
 }
 int mopk_lens_means_supported(const MopkLensMeansArgs *a, int backward) { return lens_means_supported(a, backward != 0); }
@@ -166,7 +164,7 @@ int mopk_sdpa_fwd(const MopkSdpaArgs *a, void *stream) {
     if (!v4ok(a->q) || !v4ok(a->k) || !v4ok(a->v) || !v4ok(a->y) || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (sdpa_use_flash(a, false)) return sdpa_flash_fwd(a, (hipStream_t)stream);
-    if (a->path == MOPK_PATH_FUSED || a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;   // dropout lives in the fused kernels only
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return sdpa_fwd(a, (hipStream_t)stream);
 }
 int mopk_sdpa_bwd(const MopkSdpaArgs *a, void *stream) {      // the fused path also reads `y` (the forward's output)
@@ -185,7 +183,7 @@ static int cv_validate(const MopkCrossViewArgs *a, bool bwd) {
     if (!a) return MOPK_ERR_BAD_ARG;
     int rc = base_ok(a->B, a->H, a->N, a->dk, a->io_dtype, a->precision); if (rc) return rc;
     if (!v4ok(a->q1) || !v4ok(a->k1) || !v4ok(a->v1) || !v4ok(a->q2) || !v4ok(a->k2) || !a->mix || !a->saved || !a->workspace) return MOPK_ERR_BAD_ARG;
-    if (a->anchor_mode < 0 || a->anchor_mode > 2) return MOPK_ERR_BAD_ARG;
+    if (a->anchor_mode < 0 || a->anchor_mode > 2 || a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (!bwd && !v4ok(a->y)) return MOPK_ERR_BAD_ARG;
     if (bwd && (!v4ok(a->dy) || !v4ok(a->dq1) || !v4ok(a->dk1) || !v4ok(a->dv1) || !v4ok(a->dq2) || !v4ok(a->dk2) || !a->dmix_part)) return MOPK_ERR_BAD_ARG;
     if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
@@ -208,7 +206,7 @@ int mopk_dualpath_fwd(const MopkDualPathArgs *a, void *stream) {
     if (a->hops > 0 && (!v4ok(a->v2) || !a->chain_logit)) return MOPK_ERR_BAD_ARG;
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (dp_use_flash(a)) return dp_flash_fwd(a, (hipStream_t)stream);
-    if (a->path == MOPK_PATH_FUSED || a->hops == 0 || a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;   // hops == 0 and dropout exist on the fused kernels only
+    if (a->path == MOPK_PATH_FUSED || a->hops == 0) return MOPK_ERR_UNSUPPORTED;   // hops == 0 (no transport term) exists on the fused kernels only
     return dp_fwd(a, (hipStream_t)stream);
 }
 int mopk_dualpath_bwd(const MopkDualPathArgs *a, void *stream) {
@@ -236,7 +234,7 @@ int mopk_quartet_fwd(const MopkQuartetArgs *a, void *stream) {
     if (a->use_quartet && (!v4ok(a->q2) || !v4ok(a->k2) || !a->mixture || !a->quartet_scale)) return MOPK_ERR_BAD_ARG;
     if (a->dropout_p < 0.f || a->dropout_p >= 1.f) return MOPK_ERR_BAD_ARG;
     if (qt_use_flash(a)) return qt_flash_fwd(a, (hipStream_t)stream);
-    if (a->path == MOPK_PATH_FUSED || a->dropout_p > 0.f) return MOPK_ERR_UNSUPPORTED;   // dropout lives in the fused kernels only
+    if (a->path == MOPK_PATH_FUSED) return MOPK_ERR_UNSUPPORTED;
     return qt_fwd(a, (hipStream_t)stream);
 }
 int mopk_quartet_bwd(const MopkQuartetArgs *a, void *stream) {    // the fused path also reads `y` (the forward's output)

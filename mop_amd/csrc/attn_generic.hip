@@ -93,6 +93,25 @@ static inline GemmDesc gd0(int M, int N, int K, int nb) {
     return g;
 }
 // C(N,N) = alpha * X(N,dk) Y(N,dk)^T
+// attention dropout (`self.attn_drop(A)`): out = in * keep / (1 - p) over one N x N map per (b,h), with the counter-based mask of the
+// fused kernels (common.h: a seed means one mask on either path).  In place when out == in.  One wave per row (bh, i).
+__global__ void drop_rows_kernel(const float *in, int ld_in, float *out, int ld_out, FaDrop drop, int64_t rows, int N) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t rowh = fa_drop_row(drop, (int)(row / N), (int)(row % N));
+    for (int j = lane; j < N; j += 64) out[row * ld_out + j] = fa_drop_keep(drop, rowh, j) ? in[row * ld_in + j] * drop.inv_keep : 0.f;
+}
+static void drop_map(const float *in, float *out, const Dm &d, float p, uint64_t seed, hipStream_t st) {
+    const int64_t rows = d.BH * d.N;
+    hipLaunchKernelGGL(drop_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, in, d.LD, out, d.LD, fa_drop(p, seed), rows, d.N);
+}
+// The backward of  y = drop(P) v :  dv = drop(P)^T dy  and  dP = (dy v^T) keep / (1 - p).  The dropped map is rebuilt in the dP plane
+// for the dv product BEFORE that plane receives dP (no extra workspace); the softmax backward then sees the undropped P and the
+// masked dP, as the reference's autograd does.
+static int drop_bwd_pair(const float *P, const float *dy, const float *v, float *dP, float *dv, const Dm &d, float p, uint64_t seed, bool mf,
+                         hipStream_t st);
+
 static int gemm_nt_scores(const float *X, const float *Y, float *C, const Dm &d, float alpha, bool mf, hipStream_t st, const float *adev = nullptr) {
     GemmDesc g = gd0(d.N, d.N, d.dk, (int)d.BH);
     g.A = X; g.a_rs = d.dk; g.a_cs = 1; g.a_b1 = (int64_t)d.N * d.dk;
@@ -118,6 +137,19 @@ static int gemm_map_map(const float *A, bool ta, const float *B, bool tb, float 
     return bgemm(g, mf, st);
 }
 
+static int drop_bwd_pair(const float *P, const float *dy, const float *v, float *dP, float *dv, const Dm &d, float p, uint64_t seed, bool mf,
+                         hipStream_t st) {
+    if (p > 0.f) {
+        drop_map(P, dP, d, p, seed, st);
+        RET_IF(gemm_map_vec(dP, true, dy, dv, d, 1.f, 0.f, mf, st));
+        RET_IF(gemm_nt_scores(dy, v, dP, d, 1.f, mf, st));
+        drop_map(dP, dP, d, p, seed, st);
+        return MOPK_OK;
+    }
+    RET_IF(gemm_nt_scores(dy, v, dP, d, 1.f, mf, st));
+    return gemm_map_vec(P, true, dy, dv, d, 1.f, 0.f, mf, st);
+}
+
 // =====================================================================  SDPA
 struct SdpaBuf { float *q, *k, *v, *P, *y, *dy, *dP, *dq, *dk, *dv; };
 static SdpaBuf sdpa_carve(void *saved, void *ws, const Dm &d, size_t *ns, size_t *nw) {
@@ -141,8 +173,9 @@ int sdpa_fwd(const MopkSdpaArgs *a, hipStream_t st) {
     const MaskSpec m{a->causal, a->mask, a->mask_sb, a->mask_sh, a->mask_si, a->bias, a->bias_sb, a->bias_sh, a->bias_si};
     const int64_t rows = d.BH * d.N;
     hipLaunchKernelGGL(masked_softmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.P, b.P, d, m);
+    if (a->dropout_p > 0.f) drop_map(b.P, b.dP, d, a->dropout_p, a->dropout_seed, st);     // dropped weights in a workspace plane; P stays in `saved`
     MOPK_CHECK_LAUNCH();
-    RET_IF(gemm_map_vec(b.P, false, b.v, b.y, d, 1.f, 0.f, mf, st));
+    RET_IF(gemm_map_vec(a->dropout_p > 0.f ? b.dP : b.P, false, b.v, b.y, d, 1.f, 0.f, mf, st));
     return scatter(a->io_dtype, b.y, a->y, d, st);
 }
 int sdpa_bwd(const MopkSdpaArgs *a, hipStream_t st) {
@@ -151,8 +184,7 @@ int sdpa_bwd(const MopkSdpaArgs *a, hipStream_t st) {
     const bool mf = a->precision == MOPK_PREC_BF16;
     const int64_t rows = d.BH * d.N;
     RET_IF(gather(a->io_dtype, a->dy, b.dy, d, st));
-    RET_IF(gemm_nt_scores(b.dy, b.v, b.dP, d, 1.f, mf, st));
-    RET_IF(gemm_map_vec(b.P, true, b.dy, b.dv, d, 1.f, 0.f, mf, st));
+    RET_IF(drop_bwd_pair(b.P, b.dy, b.v, b.dP, b.dv, d, a->dropout_p, a->dropout_seed, mf, st));
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.P, b.dP, d, 1.f / sqrtf((float)d.dk));
     MOPK_CHECK_LAUNCH();
     RET_IF(gemm_map_vec(b.dP, false, b.k, b.dq, d, 1.f, 0.f, mf, st));
@@ -299,7 +331,8 @@ int dp_fwd(const MopkDualPathArgs *a, hipStream_t st) {
     for (int i = 1; i < a->hops; ++i)                                                 // :224-226
         RET_IF(gemm_map_vec(b.A2, false, b.tr + (size_t)(i - 1) * nd, b.tr + (size_t)i * nd, d, 1.f, 0.f, mf, st));
     RET_IF(gemm_map_vec(b.A1, false, b.tr + (size_t)(a->hops - 1) * nd, b.ychain, d, 1.f, 0.f, mf, st));   // :227
-    RET_IF(gemm_map_vec(b.P, false, b.v1, b.ybase, d, 1.f, 0.f, mf, st));
+    if (a->dropout_p > 0.f) drop_map(b.P, b.dP, d, a->dropout_p, a->dropout_seed, st);     // :222 (the transport term uses the undropped A1, A2)
+    RET_IF(gemm_map_vec(a->dropout_p > 0.f ? b.dP : b.P, false, b.v1, b.ybase, d, 1.f, 0.f, mf, st));
     if (a->io_dtype == MOPK_BF16) hipLaunchKernelGGL((combine2_kernel<unsigned short>), dim3((nd + 255) / 256), dim3(256), 0, st, b.ybase, b.ychain, b.wsig, a->y, d);
     else hipLaunchKernelGGL((combine2_kernel<float>), dim3((nd + 255) / 256), dim3(256), 0, st, b.ybase, b.ychain, b.wsig, a->y, d);
     MOPK_CHECK_LAUNCH();
@@ -315,8 +348,7 @@ int dp_bwd(const MopkDualPathArgs *a, hipStream_t st) {
     const MaskSpec m = dp_mask(a);
     RET_IF(gather(a->io_dtype, a->dy, b.dy, d, st));
     hipLaunchKernelGGL(dot_part_kernel, dim3((int)d.BH), dim3(256), 0, st, b.dy, b.ychain, b.wsig, a->dlogit_part, (int64_t)d.N * d.dk);
-    RET_IF(gemm_nt_scores(b.dy, b.v1, b.dP, d, 1.f, mf, st));                       // dP = dy v1^T
-    RET_IF(gemm_map_vec(b.P, true, b.dy, b.dv, d, 1.f, 0.f, mf, st));               // dv1 = P^T dy
+    RET_IF(drop_bwd_pair(b.P, b.dy, b.v1, b.dP, b.dv, d, a->dropout_p, a->dropout_seed, mf, st));   // dP = dy v1^T, dv1 = P^T dy
     RET_IF(scatter(a->io_dtype, b.dv, a->dv1, d, st));
     // transport: y_chain = A1 tr_{h-1}, tr_i = A2 tr_{i-1}
     RET_IF(gemm_nt_scores(b.dy, b.tr + (size_t)(hops - 1) * nd, b.dA1, d, 1.f, mf, st, b.wsig));    // dA1 = w dy tr^T
@@ -488,8 +520,12 @@ int qt_fwd(const MopkQuartetArgs *a, hipStream_t st) {
         hipLaunchKernelGGL(znorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.z2, b.sd2, d, a->eps);
     }
     hipLaunchKernelGGL(qt_mix_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, *a, d, b);
+    if (a->dropout_p > 0.f) {                                                          // :119; the returned weights are the dropped ones (:125-126)
+        drop_map(b.P, b.dP, d, a->dropout_p, a->dropout_seed, st);
+        if (a->attn) hipLaunchKernelGGL(drop_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b.P, d.LD, a->attn, d.N, fa_drop(a->dropout_p, a->dropout_seed), rows, d.N);
+    }
     MOPK_CHECK_LAUNCH();
-    RET_IF(gemm_map_vec(b.P, false, b.v, b.y, d, 1.f, 0.f, mf, st));                   // :121
+    RET_IF(gemm_map_vec(a->dropout_p > 0.f ? b.dP : b.P, false, b.v, b.y, d, 1.f, 0.f, mf, st));   // :121
     return scatter(a->io_dtype, b.y, a->y, d, st);
 }
 int qt_bwd(const MopkQuartetArgs *a, hipStream_t st) {
@@ -499,8 +535,7 @@ int qt_bwd(const MopkQuartetArgs *a, hipStream_t st) {
     const int64_t rows = d.BH * d.N;
     const float sc = 1.f / sqrtf((float)d.dk);
     RET_IF(gather(a->io_dtype, a->dy, b.dy, d, st));
-    RET_IF(gemm_nt_scores(b.dy, b.v, b.dP, d, 1.f, mf, st));
-    RET_IF(gemm_map_vec(b.P, true, b.dy, b.dv, d, 1.f, 0.f, mf, st));
+    RET_IF(drop_bwd_pair(b.P, b.dy, b.v, b.dP, b.dv, d, a->dropout_p, a->dropout_seed, mf, st));
     RET_IF(scatter(a->io_dtype, b.dv, a->dv, d, st));
     hipLaunchKernelGGL(qt_mix_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, *a, d, b);
     MOPK_CHECK_LAUNCH();
@@ -684,8 +719,10 @@ int cv_fwd(const MopkCrossViewArgs *a, hipStream_t st) {
         hipLaunchKernelGGL(cv_anchor_kernel, dim3((unsigned)d.BH), dim3(256), 0, st, b, d, a->anchor_mode, a->fixed_k_star, a->k_star);
         hipLaunchKernelGGL(cv_sharp_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b, d, a->prior_weight);
     }
+    const float *Aw = prior ? b.A : b.P;
+    if (a->dropout_p > 0.f) { drop_map(Aw, b.dA, d, a->dropout_p, a->dropout_seed, st); Aw = b.dA; }                     // :151 (workspace plane)
     MOPK_CHECK_LAUNCH();
-    RET_IF(gemm_map_vec(prior ? b.A : b.P, false, b.v1, b.y, d, 1.f, 0.f, mf, st));                                      // :152
+    RET_IF(gemm_map_vec(Aw, false, b.v1, b.y, d, 1.f, 0.f, mf, st));                                                     // :152
     return scatter(a->io_dtype, b.y, a->y, d, st);
 }
 int cv_bwd(const MopkCrossViewArgs *a, hipStream_t st) {
@@ -697,8 +734,7 @@ int cv_bwd(const MopkCrossViewArgs *a, hipStream_t st) {
     const int64_t rows = d.BH * d.N;
     const dim3 pix((d.N * d.N + 255) / 256, (unsigned)d.BH);
     RET_IF(gather(a->io_dtype, a->dy, b.dy, d, st));
-    RET_IF(gemm_nt_scores(b.dy, b.v1, b.dA, d, 1.f, mf, st));                               // dA = dy v1^T
-    RET_IF(gemm_map_vec(prior ? b.A : b.P, true, b.dy, b.dv1, d, 1.f, 0.f, mf, st));        // dv1 = A^T dy
+    RET_IF(drop_bwd_pair(prior ? b.A : b.P, b.dy, b.v1, b.dA, b.dv1, d, a->dropout_p, a->dropout_seed, mf, st));   // dA = dy v1^T, dv1 = A^T dy
     if (prior) {
         hipLaunchKernelGGL(cv_sharp_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, b, d, a->prior_weight);
         hipLaunchKernelGGL(cv_anchor_bwd_kernel, dim3((unsigned)d.BH), dim3(256), 0, st, b, d);

@@ -50,6 +50,28 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- attention dropout: counter-based keep mask, a pure function of (seed, b*H+h, query, key) -- evaluated again in the backward
+__host__ __device__ inline uint32_t fa_hash(uint32_t x) {          // "lowbias32" integer finalizer
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct FaDrop { uint32_t thresh, seed_lo, seed_hi; float inv_keep; };      // thresh == 0: dropout off
+__host__ __device__ inline FaDrop fa_drop(float p, uint64_t seed) {
+    FaDrop d{0u, (uint32_t)seed, (uint32_t)(seed >> 32), 1.f};
+    if (p > 0.f) {
+        const double t = (double)p * 4294967296.0;
+        d.thresh = t >= 4294967295.0 ? 0xffffffffu : (t < 1.0 ? 1u : (uint32_t)t);
+        d.inv_keep = 1.f / (1.f - p);
+    }
+    return d;
+}
+__host__ __device__ inline uint32_t fa_drop_row(const FaDrop &d, int bh, int i) {
+    return fa_hash((uint32_t)i * 0x9E3779B1u + (uint32_t)bh * 0x85EBCA77u + d.seed_hi) ^ d.seed_lo;
+}
+__host__ __device__ inline bool fa_drop_keep(const FaDrop &d, uint32_t rowh, int j) {
+    return fa_hash(rowh ^ ((uint32_t)j * 0xC2B2AE3Du)) >= d.thresh;
+}
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // bump allocator over a caller-provided buffer (256-byte aligned carve-outs)

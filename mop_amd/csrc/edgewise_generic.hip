@@ -449,6 +449,15 @@ __global__ void mix_fwd_kernel(MopkEdgewiseArgs a, EwDims d, EwSaved s) {
     for (int j = lane; j < d.N; j += 64) P[j] *= inv;
 }
 
+// attn_drop on the mixed attention weights (:552): out = in * keep / (1 - p) over one N x N plane per (b,h) -- the counter-based mask
+// of the fused kernels (common.h), so a seed means one mask on either path.  In place when out == in.  One wave per row (bh, i).
+__global__ void drop_plane_kernel(const float *in, float *out, FaDrop drop, int64_t rows, int N, int LD) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t rowh = fa_drop_row(drop, (int)(row / N), (int)(row % N));
+    for (int j = lane; j < N; j += 64) out[row * LD + j] = fa_drop_keep(drop, rowh, j) ? in[row * LD + j] * drop.inv_keep : 0.f;
+}
 template <typename T>
 __global__ void combine_y_kernel(MopkEdgewiseArgs a, EwDims d, const float *ybase, const float *ychain, const float *wsig) {
     const int64_t total = d.BH * d.N * d.dk;
@@ -1142,7 +1151,12 @@ static int ew_generic_fwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
     MOPK_CHECK_LAUNCH();
     {   // y_base = P V0 ; y_chain = A0(A1(...(A_{V-1} VL))) = Cf VL      :554-560
         GemmDesc g = gd(N, dk, N, 1, BHi);
-        g.A = s.P; g.a_rs = LD; g.a_cs = 1; g.a_b1 = nn1;
+        const float *Pm = s.P;
+        if (a->dropout_p > 0.f) {        // the dropped weights go to a plane of the (backward's) workspace the forward does not use; P itself stays in `saved`
+            hipLaunchKernelGGL(drop_plane_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, s.P, w.dP, fa_drop(a->dropout_p, a->dropout_seed), rows1, N, LD);
+            Pm = w.dP;
+        }
+        g.A = Pm; g.a_rs = LD; g.a_cs = 1; g.a_b1 = nn1;
         g.B = s.V0; g.b_rs = dk; g.b_cs = 1; g.b_b1 = nd1;
         g.C = w.ybase; g.c_rs = dk; g.c_b1 = nd1;
         RET_IF(bgemm(g, mf, st));
@@ -1177,10 +1191,17 @@ static int ew_generic_bwd_t(const MopkEdgewiseArgs *a, hipStream_t st) {
         g.B = s.V0; g.b_rs = 1; g.b_cs = dk; g.b_b1 = nd1;
         g.C = w.dP; g.c_rs = LD; g.c_b1 = nn1;
         RET_IF(bgemm(g, mf, st));
+        const float *Pm = s.P;
+        if (a->dropout_p > 0.f) {        // attn_drop: dP = (dy V0^T) keep / (1 - p), and dV0 sees the dropped weights (rebuilt in a plane the D chain uses later)
+            const FaDrop drop = fa_drop(a->dropout_p, a->dropout_seed);
+            hipLaunchKernelGGL(drop_plane_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, w.dP, w.dP, drop, rows1, N, LD);
+            hipLaunchKernelGGL(drop_plane_kernel, dim3((rows1 + 3) / 4), dim3(256), 0, st, s.P, w.D0, drop, rows1, N, LD);
+            Pm = w.D0;
+        }
         g.B = s.VL; g.C = w.dCf; g.alpha_dev = s.wsig;   // dCf = w dy VL^T
         RET_IF(bgemm(g, mf, st));
         GemmDesc h = gd(N, dk, N, 1, BHi);           // dV0 = P^T dy
-        h.A = s.P; h.a_rs = 1; h.a_cs = LD; h.a_b1 = nn1;
+        h.A = Pm; h.a_rs = 1; h.a_cs = LD; h.a_b1 = nn1;
         h.B = w.dyc; h.b_rs = dk; h.b_cs = 1; h.b_b1 = nd1;
         h.C = w.dV0; h.c_rs = dk; h.c_b1 = nd1;
         RET_IF(bgemm(h, mf, st));

@@ -15,9 +15,8 @@ qkv projection and the output projection is one C-ABI call (mop_amd/ops.py).
 The plain dense gate head runs on the fused kernels like the low-rank head; `use_k3` and the S lens bank run inside the library's
 generic path; the Q/K lens bank's depthwise token convolutions (:472-498) are torch ops feeding per-view q/k to the same core.
 An `attn_mask` on EdgewiseMSA is an extension (the reference is NaN there, SURVEY.md 8a note): the mask acts on the probabilities
-only, generic path.  Attention dropout (`attn_drop > 0` in training mode) runs inside every fused kernel family; the combinations
-that fall to the generic path (use_k3 / lens Edgewise, masked Edgewise, CrossViewMixer with cues or prior) raise
-NotImplementedError for it instead of training without dropout ("Dropout").
+only, generic path.  Attention dropout (`attn_drop > 0` in training mode) is a counter-based keep mask that both paths of every
+core evaluate from one seed: inside the fused kernels, and on the generic paths as a multiply of the N x N map ("Dropout").
 """
 from __future__ import annotations
 
@@ -169,14 +168,9 @@ class EdgewiseMSA(nn.Module):
         # so its output is NaN for any blocking mask (SURVEY.md 8a note).  Here the mask (0 = blocked) acts on the attention
         # probabilities only -- the per-view softmaxes and the final one -- while the gate features see the unmasked scores; it runs on
         # the generic path, and every query must keep at least one key (a causal mask does).
-        if attn_mask is not None and self.training and self.attn_drop.p > 0:
-            raise NotImplementedError("attn_drop > 0 in training mode with attn_mask: the generic path does not carry dropout")
         if self.use_lens_bank and self.lens_kernel_size != 3:
             raise ValueError("lens_kernel_size must be 3: with padding = dilation any other size changes the plane size and "
                              "the reference's feature stack (:534) cannot be built")
-        if self.training and self.attn_drop.p > 0 and self.edge_head.gate_mode == "dense" and (self.use_lens_bank or self.edge_head.use_k3):
-            raise NotImplementedError("attn_drop > 0 in training mode: the fused kernels carry it (low-rank head with or without the S lens "
-                                      "bank, plain dense head); the dense head's use_k3 / lens-bank variants (generic path) do not")
 
     def _qk_lens_views(self, qkv: torch.Tensor) -> torch.Tensor:
         """Q/K lens bank (:472-498): depthwise dilated convolutions over the token axis of view-0 q and k build one

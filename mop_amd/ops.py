@@ -206,9 +206,6 @@ class _EdgewiseLowrankFn(torch.autograd.Function):
         if path == L.PATH_AUTO:   # AUTO: fused gfx950 kernels when they cover the shape, generic otherwise
             path = L.PATH_FUSED if lib.mopk_edgewise_fused_supported(C.byref(a)) else L.PATH_GENERIC
         a.path = path
-        if drop[0] > 0 and path != L.PATH_FUSED:
-            raise NotImplementedError("attn_drop > 0 in training mode runs in the fused bf16 Edgewise kernels only (low-rank head, "
-                                      "shared qkv, N <= 224, dk 16/32/64, bf16 arithmetic)")
         a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         # training forward of the fused path also exports the chain state its backward would otherwise recompute
         a.save_for_backward = int(bool(want_bwd) and path == L.PATH_FUSED and _SAVE_CHAIN_STATE)
@@ -348,9 +345,6 @@ class _EdgewiseGeneralFn(torch.autograd.Function):
             a.path, a.save_for_backward = L.PATH_FUSED, 1
             if not lib.mopk_edgewise_fused_supported(C.byref(a)):
                 a.path, a.save_for_backward = L.PATH_GENERIC, 0
-        if drop[0] > 0 and a.path != L.PATH_FUSED:
-            raise NotImplementedError("attn_drop > 0 in training mode: carried by the fused kernels only (low-rank head, or the dense "
-                                      "head without use_k3 / lens banks at V <= 6, bf16 arithmetic)")
         a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         LAST_PATH["edgewise_fwd"] = int(a.path)
         saved = _bytes(lib.mopk_edgewise_saved_bytes(C.byref(a)), dev)
@@ -724,9 +718,6 @@ class _SdpaFn(torch.autograd.Function):
         if path == L.PATH_AUTO:       # resolve once so forward, backward and the size queries agree
             path = L.PATH_FUSED if lib.mopk_sdpa_fused_supported(C.byref(a)) else L.PATH_GENERIC
             a.path = path
-        if drop[0] > 0 and path != L.PATH_FUSED:
-            raise NotImplementedError("attention dropout runs in the fused bf16 kernels only (dk 32/64, bf16 arithmetic): "
-                                      "use bf16 tensors / set_precision('bf16'), or attn_drop = 0")
         LAST_PATH["sdpa_fwd"] = path
         saved = _bytes(lib.mopk_sdpa_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_sdpa_workspace_bytes(C.byref(a)), dev)
@@ -808,7 +799,7 @@ class _CrossViewFn(torch.autograd.Function):
     """CrossViewMixerMSA core, reference attention_variants.py:90-153."""
 
     @staticmethod
-    def forward(ctx, q1, k1, v1, q2, k2, mix, cfg, mask, causal, prec):
+    def forward(ctx, q1, k1, v1, q2, k2, mix, cfg, mask, causal, prec, drop=(0.0, 0)):
         _require_gpu(q1, "CrossViewMixerMSA")
         lib = L.lib()
         ts = [_heads_view(t) for t in (q1, k1, v1, q2, k2)]
@@ -823,6 +814,7 @@ class _CrossViewFn(torch.autograd.Function):
         a.mix = mx.data_ptr()
         m8, ms = _mask_u8(mask, B, H, N, dev)
         a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         y = torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev)
         a.y = _v4(y)
         kst = torch.zeros(B, H, dtype=torch.int32, device=dev)
@@ -835,14 +827,14 @@ class _CrossViewFn(torch.autograd.Function):
         L.check(rc, "mopk_crossview_fwd")
         LAST_PATH["crossview_k_star"] = kst
         ctx.save_for_backward(*ts, mx, saved)
-        ctx.meta = (cfg, causal, prec, m8, ms)
+        ctx.meta = (cfg, causal, prec, m8, ms, drop)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.lib()
         *ts, mx, saved = ctx.saved_tensors
-        cfg, causal, prec, m8, ms = ctx.meta
+        cfg, causal, prec, m8, ms, drop = ctx.meta
         B, N, H, dk = ts[0].shape
         dev = ts[0].device
         dy = dy.contiguous().to(ts[0].dtype).view(B, N, H, dk)
@@ -853,6 +845,7 @@ class _CrossViewFn(torch.autograd.Function):
         a.q1, a.k1, a.v1, a.q2, a.k2 = (_v4(t) for t in ts)
         a.mix = mx.data_ptr()
         a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         a.y, a.dy = _v4(dy), _v4(dy)
         outs = [torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(5)]
         a.dq1, a.dk1, a.dv1, a.dq2, a.dk2 = (_v4(t) for t in outs)
@@ -863,7 +856,7 @@ class _CrossViewFn(torch.autograd.Function):
         with _timed("crossview_bwd"):
             rc = lib.mopk_crossview_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_crossview_bwd")
-        return (*outs, dmix.sum((0, 1)).view(2, 2), None, None, None, None)
+        return (*outs, dmix.sum((0, 1)).view(2, 2), None, None, None, None, None)
 
 
 @_half_via_fp32
@@ -884,12 +877,9 @@ def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, an
         zero = q1.new_zeros((), dtype=torch.float32)
         LAST_PATH["crossview_fwd"] = L.PATH_FUSED
         return _DualPathFn.apply(q1, k1p, v1, q2, k2p, v1, zero, (1.0, 0.0, 0.0, 0.0), 0.0, 0, attn_mask, causal, prec, L.PATH_FUSED, drop)
-    if drop[0] > 0:
-        raise NotImplementedError("attn_drop > 0 in training mode: CrossViewMixerMSA carries it on its fused path only (no transpose "
-                                  "cues, no per-key prior, bf16 arithmetic, dk 32/64)")
     LAST_PATH["crossview_fwd"] = L.PATH_GENERIC
     cfg = (float(t1), float(t2), float(prior_weight), int(prior_weight > 0.0), _ANCHOR_MODES.get(anchor_mode, 2), int(fixed_k_star))
-    return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, prec)
+    return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, prec, drop)
 
 
 class _DualPathFn(torch.autograd.Function):
@@ -915,9 +905,6 @@ class _DualPathFn(torch.autograd.Function):
         if path == L.PATH_AUTO:
             path = L.PATH_FUSED if lib.mopk_dualpath_fused_supported(C.byref(a)) else L.PATH_GENERIC
             a.path = path
-        if drop[0] > 0 and path != L.PATH_FUSED:
-            raise NotImplementedError("attn_drop > 0 in training mode runs in the fused bf16 kernels only (dk 32/64, chain gate 0, "
-                                      "bf16 arithmetic)")
         a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         LAST_PATH["dualpath_fwd"] = path
         saved = _bytes(lib.mopk_dualpath_saved_bytes(C.byref(a)), dev)
@@ -999,9 +986,6 @@ class _QuartetFn(torch.autograd.Function):
         if path == L.PATH_AUTO:
             path = L.PATH_FUSED if lib.mopk_quartet_fused_supported(C.byref(a)) else L.PATH_GENERIC
             a.path = path
-        if drop[0] > 0 and path != L.PATH_FUSED:
-            raise NotImplementedError("attention dropout runs in the fused bf16 Quartet kernels only (head dim 32/64, bf16 arithmetic, "
-                                      "need_weights=False): use bf16 tensors / set_precision('bf16'), or dropout = 0")
         LAST_PATH["quartet_fwd"] = path
         saved = _bytes(lib.mopk_quartet_saved_bytes(C.byref(a)), dev)
         ws = _bytes(lib.mopk_quartet_workspace_bytes(C.byref(a)), dev)

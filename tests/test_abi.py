@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.mopk_version() == 117
+    assert lib.mopk_version() == 118
     assert lib.mopk_strerror(0) == b"ok"
     assert b"shape" in lib.mopk_strerror(-1)
 

@@ -214,6 +214,162 @@ def test_crossview_and_multihop_modules_train_with_attention_dropout():
             m.eval()
             e1, e2 = m(x), m(x)
         assert torch.equal(e1, e2) and not torch.equal(t1.detach(), t2) and torch.isfinite(xi.grad).all()
-    cues = CrossViewMixerMSA(128, 2, attn_drop=0.2, use_transpose_cues=True, t1=0.3).cuda().to(torch.bfloat16).train()
-    with pytest.raises(NotImplementedError, match="attn_drop"):
-        cues(x)
+
+
+
+# ---- generic paths (round 3): the same mask from the same seed, applied to the N x N map in a workspace plane -------------------------
+def _pair(fn):
+    """run fn() on the generic path and on the path the library picks; -> (generic, picked) results"""
+    from mop_amd import ops
+    out = []
+    for path in ("generic", "auto"):
+        ops.set_path(path)
+        try:
+            out.append(fn())
+        finally:
+            ops.set_path("auto")
+    return out
+
+
+def _close(a, b, tol):
+    a, b = a.detach().float(), b.detach().float()
+    return float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
+def test_generic_paths_draw_the_fused_kernels_mask():
+    """SDPA, dual-path (MultiHopMSA) and Quartet cores: with one seed the generic multi-kernel path and the fused kernels drop the same
+    weights -- outputs and input gradients agree to bf16 accuracy (they would differ by O(1) under different masks)."""
+    import mop_amd
+    from mop_amd import ops
+    mop_amd.set_precision("bf16")
+    try:
+        torch.manual_seed(9)
+        B, N, H, dk, p, seed = 2, 96, 2, 64, 0.3, 424242424242
+        mk = lambda: torch.randn(B, N, H, dk, device="cuda", dtype=torch.bfloat16).requires_grad_(True)
+        w = torch.randn(B, N, H * dk, device="cuda", dtype=torch.bfloat16)
+
+        def run(core, ts, *args, **kw):
+            for t in ts:
+                t.grad = None
+            y = core(*ts, *args, dropout_p=p, seed=seed, **kw)
+            y.backward(w)
+            return [y] + [t.grad.clone() for t in ts]
+
+        q, k, v = mk(), mk(), mk()
+        g, f = _pair(lambda: (run(ops.sdpa_core, [q, k, v], causal=True), ops.LAST_PATH["sdpa_fwd"]))
+        assert (g[1], f[1]) == (1, 2) and all(_close(x, y, 3e-2) for x, y in zip(g[0], f[0]))
+        y0 = ops.sdpa_core(q, k, v, causal=True)
+        assert not _close(g[0][0], y0, 3e-2)                      # and the mask bites on the generic path
+
+        ts = [mk() for _ in range(6)]
+        logit = torch.tensor(-0.5, device="cuda")
+        g, f = _pair(lambda: (run(lambda *a, **kw: ops.dualpath_core(*a[:6], logit, 1.0, 0.3, 0.2, 0.0, 0.5, 3, **kw), ts), ops.LAST_PATH["dualpath_fwd"]))
+        assert (g[1], f[1]) == (1, 2) and all(_close(x, y, 4e-2) for x, y in zip(g[0], f[0]))
+
+        ts = [mk() for _ in range(5)]
+        mix, qs = torch.tensor([0.3], device="cuda"), torch.tensor([1.2], device="cuda")
+        g, f = _pair(lambda: (run(lambda q_, k_, v_, q2, k2, **kw: ops.quartet_core(q_, k_, v_, q2, k2, mix, qs, None, 1e-5, True, **kw), ts),
+                              ops.LAST_PATH["quartet_fwd"]))
+        assert (g[1], f[1]) == (1, 2) and all(_close(x, y, 4e-2) for x, y in zip(g[0], f[0]))
+    finally:
+        mop_amd.set_precision("auto")
+
+
+@pytest.mark.parametrize("variant", ["lowrank", "dense_k3_lens_mask"])
+def test_edgewise_generic_path_dropout(variant):
+    """EdgewiseMSA with attn_drop > 0 in training mode on the generic path (:552).  Low-rank head: the generic path against the fused
+    kernels under one seed.  Dense head + use_k3 + S lens bank + attn_mask (generic only): against the float64 oracle run under the
+    same mask."""
+    import mop_amd
+    from mop_amd import ops
+    from mop_amd.nn import EdgewiseMSA
+    from oracle import edgewise as O
+    D, Hh, V, N, B, p = 64, 2, 3, 40, 2, 0.25
+    torch.manual_seed(33)
+    if variant == "lowrank":
+        m = EdgewiseMSA(D, Hh, attn_drop=p, n_views=V, share_qkv=True, gate_mode="lowrank", gate_rank=2, gate_init="mix5")
+    else:
+        m = EdgewiseMSA(D, Hh, attn_drop=p, n_views=V, share_qkv=True, gate_mode="dense", use_k3=True, gate_init="and", use_lens_bank=True,
+                        lens_dilations=(1, 2))
+    with torch.no_grad():
+        for n_, prm in m.named_parameters():
+            prm.add_(0.1 * torch.randn_like(prm))
+            if n_.endswith("conv2.bias"):
+                prm.copy_(0.7 * torch.randn_like(prm))
+    x, w = torch.randn(B, N, D), torch.randn(B, N, D)
+    if variant == "lowrank":
+        mop_amd.set_precision("bf16")
+        try:
+            mg = m.cuda().to(torch.bfloat16).train()
+
+            def step():
+                xg = x.cuda().to(torch.bfloat16).requires_grad_(True)
+                mg.zero_grad()
+                torch.manual_seed(5)                        # the module draws its mask seed from torch's generator
+                y = mg(xg)
+                y.backward(w.cuda().to(torch.bfloat16))
+                return [y, xg.grad] + [prm.grad.clone() for prm in mg.parameters()], ops.LAST_PATH["edgewise_fwd"]
+            g, f = _pair(step)
+        finally:
+            mop_amd.set_precision("auto")
+        assert (g[1], f[1]) == (1, 2)
+        assert _close(g[0][0], f[0][0], 2e-2) and _close(g[0][1], f[0][1], 4e-2)
+        return
+    mop_amd.set_precision("fp32")
+    try:
+        params = {k: v.detach().numpy().astype(np.float64) for k, v in m.state_dict().items()}
+        mask = torch.ones(N, N).tril_()
+        mg = m.cuda().train()
+        xg = x.cuda().requires_grad_(True)
+        torch.manual_seed(77)
+        seed = ops.dropout_seed()
+        torch.manual_seed(77)
+        y = mg(xg, attn_mask=mask.cuda())
+        assert ops.LAST_PATH["edgewise_fwd"] == 1
+        y.backward(w.cuda())
+    finally:
+        mop_amd.set_precision("auto")
+    drop = ops.dropout_keep_mask(seed, p, B, Hh, N).numpy().astype(np.float64) / (1.0 - p)
+    yr, c = O.module_fwd(x.double().numpy(), params, Hh, V, True, 0.5, lens_dilations=(1, 2), attn_mask=mask.numpy(), drop=drop)
+    dxr, gr = O.module_bwd(w.double().numpy(), c)
+    assert max_abs(y.detach().cpu().numpy(), yr) <= 1e-4 and rel_err(xg.grad.cpu().numpy(), dxr) <= 1e-3
+    for k_, prm in mg.named_parameters():
+        assert rel_err(prm.grad.cpu().numpy().reshape(gr[k_].shape), gr[k_]) <= 1e-3 or max_abs(prm.grad.cpu().numpy().reshape(gr[k_].shape), gr[k_]) <= 1e-6, k_
+
+
+def test_crossview_cues_and_prior_dropout_vs_autograd():
+    """CrossViewMixerMSA core with transpose cues / the per-key prior (generic path) and attn_drop: against the reference's formula
+    (:99-110, :124-152) written in torch float64 with the library's mask, gradients by autograd."""
+    import mop_amd
+    from mop_amd import ops
+    torch.manual_seed(4)
+    B, N, H, dk, p, seed = 2, 33, 2, 16, 0.2, 1357913579
+    mop_amd.set_precision("fp32")
+    try:
+        for t1, t2, pw in ((0.3, -0.2, 0.0), (0.0, 0.0, 0.5)):
+            ts = [torch.randn(B, N, H, dk, device="cuda").requires_grad_(True) for _ in range(5)]
+            mix = torch.tensor([[1.0, 0.2], [-0.3, 0.8]], device="cuda", requires_grad=True)
+            w = torch.randn(B, N, H * dk, device="cuda")
+            y = ops.crossview_core(*ts, mix, t1=t1, t2=t2, prior_weight=pw, anchor_mode="fixed", fixed_k_star=3, dropout_p=p, seed=seed)
+            assert ops.LAST_PATH["crossview_fwd"] == 1
+            y.backward(w)
+            got = [y.detach()] + [t.grad.clone() for t in ts] + [mix.grad.clone()]
+            q1, k1, v1, q2, k2 = (t.detach().double().permute(0, 2, 1, 3).requires_grad_(True) for t in ts)
+            mx = mix.detach().double().requires_grad_(True)
+            sc = dk ** -0.5
+            S1, S2 = q1 @ k1.transpose(-1, -2) * sc, q2 @ k2.transpose(-1, -2) * sc
+            S12, S21 = q1 @ k2.transpose(-1, -2) * sc, q2 @ k1.transpose(-1, -2) * sc
+            S = mx[0, 0] * S1 + mx[0, 1] * S12 + mx[1, 0] * S21 + mx[1, 1] * S2 + t1 * S1.transpose(-1, -2) + t2 * S2.transpose(-1, -2)
+            A = torch.softmax(S, -1)
+            if pw > 0:
+                A1, A2 = torch.softmax(S1, -1), torch.softmax(S2, -1)
+                sharp = A1 * A2[:, :, 3:4, :]
+                A = (1 - pw) * A + pw * sharp / (sharp.sum(-1, keepdim=True) + 1e-9)
+            keep = ops.dropout_keep_mask(seed, p, B, H, N).to("cuda").double() / (1 - p)
+            yr = ((A * keep) @ v1).permute(0, 2, 1, 3).reshape(B, N, H * dk)
+            yr.backward(w.double())
+            ref = [yr.detach()] + [t.grad.permute(0, 2, 1, 3) for t in (q1, k1, v1, q2, k2)] + [mx.grad]
+            for a_, b_ in zip(got, ref):
+                assert float((a_.double() - b_).abs().max()) <= 1e-3 * max(1.0, float(b_.abs().max()))
+    finally:
+        mop_amd.set_precision("auto")

@@ -90,7 +90,7 @@ def test_unsupported_variants_raise_instead_of_falling_back():
     x = torch.randn(1, 8, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):   # masked Edgewise (an extension, generic path) -- still never on the CPU
         EdgewiseMSA(64, 4, gate_mode="lowrank", share_qkv=True)(x, attn_mask=torch.ones(8, 8))
-    with pytest.raises(NotImplementedError, match="attn_mask"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):   # ... with attn_drop in training mode too (the generic path carries dropout)
         EdgewiseMSA(64, 4, attn_drop=0.1, gate_mode="lowrank", share_qkv=True).train()(x, attn_mask=torch.ones(8, 8))
     with pytest.raises(ValueError):      # reference: torch.stack fails for lens_kernel_size != 3 (:534)
         EdgewiseMSA(64, 4, gate_mode="lowrank", share_qkv=True, use_lens_bank=True, lens_kernel_size=5)(x)
@@ -98,13 +98,13 @@ def test_unsupported_variants_raise_instead_of_falling_back():
         EdgewiseMSA(64, 4, gate_mode="dense")(x)
 
 
-def test_attention_dropout_in_training_raises_where_the_kernels_do_not_carry_it():
-    """the reference applies attn_drop to the attention weights (attention_variants.py:45, :153, :222, :552).  The fused kernels carry
-    it (tests/test_gpu_dropout.py); configurations that run the generic path refuse it instead of silently training a different
-    model -- e.g. the dense gate head."""
+def test_attention_dropout_in_training_is_never_silently_skipped():
+    """the reference applies attn_drop to the attention weights (attention_variants.py:45, :153, :222, :552).  Every path of the library
+    carries it (tests/test_gpu_dropout.py); a module in training mode with attn_drop > 0 therefore reaches the library (and, on a CPU
+    tensor, its loud no-fallback error) instead of quietly training a different model."""
     from mop_amd.nn import EdgewiseMSA
     m = EdgewiseMSA(64, 4, attn_drop=0.1, gate_mode="dense", use_k3=True).train()
-    with pytest.raises(NotImplementedError, match="attn_drop"):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.randn(1, 8, 64))
 
 
