@@ -17,7 +17,8 @@ for spec in sys.argv[3:]:
     stem, nt, dk = spec.split(":")
     obj = f"{stem}_nt{nt}_dk{dk}.o"
     out = os.path.join(b.OBJ, name, obj)
-    cmd = [cc] + b.FLAGS + ["-ffast-math", "-fno-finite-math-only", f"-DMOPK_INST_NT={nt}", f"-DMOPK_INST_DK={dk}"] + extra + \
+    base = [f for f in b.FLAGS if not (f.startswith("--offload-arch=") and any(e.startswith("--offload-arch=") for e in extra))]   # an arch in `extra` replaces the default one
+    cmd = [cc] + base + ["-ffast-math", "-fno-finite-math-only", f"-DMOPK_INST_NT={nt}", f"-DMOPK_INST_DK={dk}"] + extra + \
           ["-c", "-o", out, os.path.join(b.CSRC, stem + ".hip")]
     subprocess.run(cmd, check=True)
     swaps[obj] = out
