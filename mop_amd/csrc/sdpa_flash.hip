@@ -289,8 +289,8 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 1 : 2) sdpa_flash_dkv_kerne
     constexpr int DT = DK / 32, LDK = DK + 8;
     __shared__ __attribute__((aligned(16))) unsigned short Qs[FA_KT * LDK], Gs[FA_KT * LDK], Qt[DK * FA_LDT], Gt[DK * FA_LDT];
     __shared__ __attribute__((aligned(16))) unsigned short Q2s[DUAL ? FA_KT * LDK : 8], Q2t[DUAL ? DK * FA_LDT : 8];
-    __shared__ float Ls[FA_KT], Ds[FA_KT];
-    __shared__ uint32_t Hs[FA_KT];                 // dropout row hashes of the tile's queries
+    __shared__ __attribute__((aligned(16))) float Ls[FA_KT], Ds[FA_KT];      // 16-byte aligned: the four consecutive rows of a register quad are one ds_read_b128
+    __shared__ __attribute__((aligned(16))) uint32_t Hs[FA_KT];              // dropout row hashes of the tile's queries
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int N = a.N;
     int kb, bh;
@@ -348,17 +348,24 @@ __global__ void __launch_bounds__(FA_NW * 64, DUAL ? 1 : 2) sdpa_flash_dkv_kerne
             f32x16 T2 = fa_zero();
             if (DUAL) T2 = fa_mm_rows<DK>(Q2s, 32 * s2, r, h, *(const bf16x8(*)[DK / 16]) & k2f);
             f32x16 P, dS, dS2;
+            float lrow[16], drow[16];                                // row statistics of the tile's 16 registers: rows 8 q + 4 h + {0..3} per quad q
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 l4 = *(const float4 *)&Ls[32 * s2 + 8 * q4 + 4 * h], d4 = *(const float4 *)&Ds[32 * s2 + 8 * q4 + 4 * h];
+                lrow[4 * q4] = l4.x; lrow[4 * q4 + 1] = l4.y; lrow[4 * q4 + 2] = l4.z; lrow[4 * q4 + 3] = l4.w;
+                drow[4 * q4] = d4.x; drow[4 * q4 + 1] = d4.y; drow[4 * q4 + 2] = d4.z; drow[4 * q4 + 3] = d4.w;
+            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int il = 32 * s2 + tile_row(g, h), i = i0 + il;
                 bool ok = kok && i < N && (!CAUSAL || kj <= i);
                 float z = DUAL ? fa_mix(S[g], T2[g], u.a2, u.g_or) : S[g];
                 if (MB) { bool blk; z = fa_apply_mb(z, mb, a, i, kj, blk); ok = ok && !blk; }
-                const float p = ok ? __builtin_amdgcn_exp2f(z - Ls[il]) : 0.f;
+                const float p = ok ? __builtin_amdgcn_exp2f(z - lrow[g]) : 0.f;
                 float dp = dP[g], pd = p;                         // dropout: dV sees P keep / (1 - p), dP = (dy v^T) keep / (1 - p)
                 if (drop.thresh) { const float kp = fa_drop_keep(drop, Hs[il], kj) ? drop.inv_keep : 0.f; dp *= kp; pd *= kp; }
                 P[g] = pd;
-                const float dz = p * (dp - Ds[il]) * FA_LN2;      // Q' = q log2(e)/sqrt(dk)  ->  dK = (dS ln2)^T Q'
+                const float dz = p * (dp - drow[g]) * FA_LN2;     // Q' = q log2(e)/sqrt(dk)  ->  dK = (dS ln2)^T Q'
                 if (DUAL) { float c1, c2; fa_mix_grad(S[g], T2[g], u.a2, u.g_or, c1, c2); dS[g] = dz * c1; dS2[g] = dz * c2; }
                 else dS[g] = dz;
             }
