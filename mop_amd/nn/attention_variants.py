@@ -269,7 +269,7 @@ class BaselineMSA(nn.Module):
         B, N, D = x.shape
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
         causal = _is_causal_mask(attn_mask, N)      # tril mask -> in-kernel causal flag (keeps the call on the fused kernels)
-        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], None if causal else attn_mask, causal=causal, dropout_p=pdrop)
+        y = ops.sdpa_core(qkv, attn_mask=None if causal else attn_mask, causal=causal, dropout_p=pdrop)     # packed q | k | v: one gradient tensor back
         return self.proj_drop(self.proj(y))
 
 
@@ -298,7 +298,7 @@ class MultiHopMSA(nn.Module):
         qkv2 = self.qkv2(x).view(B, N, 3, self.h, self.dk)
         g = self.gates
         causal = _is_causal_mask(attn_mask, N)      # a lower-triangular mask becomes the in-kernel causal flag (fused path)
-        y = ops.dualpath_core(qkv1[:, :, 0], qkv1[:, :, 1], qkv1[:, :, 2], qkv2[:, :, 0], qkv2[:, :, 1], qkv2[:, :, 2],
+        y = ops.dualpath_core(qkv1, None, None, qkv2, None, None,      # packed q | k | v of each projection: two gradient tensors back
                               self.chain_value_logit, g.get("and_", 1.0), g.get("or_", 0.0),
                               g.get("not_", 0.0), g.get("chain", 0.0), self.beta_not, self.hops,
                               None if causal else attn_mask, causal=causal, dropout_p=pdrop)
@@ -333,7 +333,7 @@ class CrossViewMixerMSA(nn.Module):
         cues = self.use_transpose_cues
         pw = self.prior_weight if (self.enable_per_key_prior and self.prior_weight > 0.0) else 0.0     # :126
         causal = _is_causal_mask(attn_mask, N)
-        y = ops.crossview_core(a[:, :, 0], a[:, :, 1], a[:, :, 2], b[:, :, 0], b[:, :, 1], self.mix,
+        y = ops.crossview_core_packed(a, b, self.mix,
                                t1=self.t1 if cues else 0.0, t2=self.t2 if cues else 0.0, prior_weight=pw,
                                anchor_mode=self.anchor_mode, fixed_k_star=self.fixed_k_star,
                                attn_mask=None if causal else attn_mask, causal=causal, dropout_p=pdrop)

@@ -55,7 +55,7 @@ class MSA(nn.Module):
         B, N, D = x.shape
         pdrop = float(self.attn_drop.p) if self.training else 0.0      # self.attn_drop(A) (:62), inside the kernels
         qkv = self.qkv(x).view(B, N, 3, self.h, self.dk)
-        y = ops.sdpa_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p=pdrop)
+        y = ops.sdpa_core(qkv, dropout_p=pdrop)                       # packed q | k | v: one gradient tensor back
         if residual is None:
             return self.proj_drop(self.proj(y))
         if y.is_cuda and y.dtype == residual.dtype == self.proj.weight.dtype and not torch.is_autocast_enabled() \

@@ -701,6 +701,11 @@ class _SdpaFn(torch.autograd.Function):
     def forward(ctx, q, k, v, mask, bias, causal, prec, path, drop=(0.0, 0)):
         _require_gpu(q, "SDPA")
         lib = L.lib()
+        # packed form: q is the (B,N,3,H,dk) output of one qkv projection and k = v = None.  The kernels read the three strided views and
+        # the backward writes ONE packed gradient -- autograd then has no per-view zero-fill + copy + add to assemble it from three
+        ctx.packed = k is None
+        if ctx.packed:
+            q, k, v = q.contiguous().unbind(2)
         q, k, v = _heads_view(q), _heads_view(k), _heads_view(v)
         B, N, H, dk = q.shape
         dev = q.device
@@ -744,7 +749,11 @@ class _SdpaFn(torch.autograd.Function):
         a.q, a.k, a.v, a.y, a.dy = _v4(q), _v4(k), _v4(v), _v4(y), _v4(dy)
         a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
         a.bias, (a.bias_sb, a.bias_sh, a.bias_si) = _ptr(bf), bs
-        dq, dk_, dv = (torch.empty(B, N, H, dk, dtype=q.dtype, device=dev) for _ in range(3))
+        if ctx.packed:
+            dqkv = torch.empty(B, N, 3, H, dk, dtype=q.dtype, device=dev)
+            dq, dk_, dv = dqkv.unbind(2)
+        else:
+            dq, dk_, dv = (torch.empty(B, N, H, dk, dtype=q.dtype, device=dev) for _ in range(3))
         a.dq, a.dk_, a.dv = _v4(dq), _v4(dk_), _v4(dv)
         LAST_PATH["sdpa_bwd"] = path
         ws = _bytes(lib.mopk_sdpa_workspace_bytes(C.byref(a)), dev)
@@ -752,6 +761,8 @@ class _SdpaFn(torch.autograd.Function):
         with _timed("sdpa_bwd"):
             rc = lib.mopk_sdpa_bwd(C.byref(a), _stream())
         L.check(rc, "mopk_sdpa_bwd")
+        if ctx.packed:
+            return dqkv, None, None, None, None, None, None, None, None
         return dq, dk_, dv, None, None, None, None, None, None
 
 
@@ -783,10 +794,13 @@ def dropout_keep_mask(seed: int, p: float, B: int, H: int, N: int) -> torch.Tens
 
 
 @_half_via_fp32
-def sdpa_core(q, k, v, attn_mask=None, bias=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
-    """q,k,v: (B,N,H,dk) views. Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive.  dropout_p > 0: the probabilities
-    are multiplied by keep / (1 - p) inside the fused kernels (mask = `dropout_keep_mask(seed, ...)`, seed drawn when None)."""
+def sdpa_core(q, k=None, v=None, attn_mask=None, bias=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
+    """q,k,v: (B,N,H,dk) views -- or packed: q = the (B,N,3,H,dk) output of one qkv projection, k = v = None (one packed gradient comes
+    back).  Returns (B,N,H*dk).  attn_mask: 0 = blocked; bias: additive.  dropout_p > 0: the probabilities are multiplied by
+    keep / (1 - p) (mask = `dropout_keep_mask(seed, ...)`, seed drawn when None)."""
     if q.shape[0] == 0:
+        if k is None:
+            return _empty_batch(q, 0, q.shape[1], q.shape[-2] * q.shape[-1])
         return _empty_batch(q, 0, q.shape[1], q.shape[2] * q.shape[3]) + (k.sum() + v.sum()) * 0
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     return _SdpaFn.apply(q, k, v, attn_mask, bias, causal, _prec_for(q.dtype), _PATH, drop)
@@ -882,77 +896,169 @@ def crossview_core(q1, k1, v1, q2, k2, mix, t1=0.0, t2=0.0, prior_weight=0.0, an
     return _CrossViewFn.apply(q1, k1, v1, q2, k2, mix, cfg, attn_mask, causal, prec, drop)
 
 
+@_half_via_fp32
+def crossview_core_packed(qkv1, qkv2, mix, t1=0.0, t2=0.0, prior_weight=0.0, anchor_mode="argmax_row_sum", fixed_k_star=0,
+                          attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
+    """`crossview_core` from the packed (B,N,3,H,dk) outputs of the two qkv projections: on the fused route (no transpose cues, no
+    prior, bf16 arithmetic, dk 32 / 64) one Function builds the mixed keys, runs the two-score kernels and hands back ONE gradient per
+    projection; otherwise the views go to `crossview_core`."""
+    if qkv1.shape[0] == 0:
+        return _empty_batch(qkv1, 0, qkv1.shape[1], qkv1.shape[-2] * qkv1.shape[-1])
+    prec = _prec_for(qkv1.dtype)
+    if (prior_weight <= 0.0 and t1 == 0.0 and t2 == 0.0 and _PATH != L.PATH_GENERIC and prec == L.PREC_BF16
+            and qkv1.shape[-1] in (32, 64) and qkv1.dtype != torch.float16):
+        drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
+        LAST_PATH["crossview_fwd"] = L.PATH_FUSED
+        return _CrossViewFoldedFn.apply(qkv1, qkv2, mix, attn_mask, causal, prec, drop)
+    return crossview_core(qkv1[:, :, 0], qkv1[:, :, 1], qkv1[:, :, 2], qkv2[:, :, 0], qkv2[:, :, 1], mix, t1=t1, t2=t2,
+                          prior_weight=prior_weight, anchor_mode=anchor_mode, fixed_k_star=fixed_k_star, attn_mask=attn_mask, causal=causal,
+                          dropout_p=dropout_p, seed=seed)
+
+
+def _dp_fwd(ts, lg, gates, beta_not, hops, m8, ms, causal, prec, path, drop):
+    """one mopk_dualpath_fwd call on six (B,N,H,dk) views -> (y (B,N,H,dk), saved, resolved path)"""
+    lib = L.lib()
+    B, N, H, dk = ts[0].shape
+    dev = ts[0].device
+    a = L.DualPathArgs()
+    a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
+    a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, path, int(bool(causal))
+    a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
+    a.beta_not = float(beta_not)
+    a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
+    a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+    a.chain_logit = lg.data_ptr()
+    y = torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev)
+    a.y = _v4(y)
+    if path == L.PATH_AUTO:
+        path = L.PATH_FUSED if lib.mopk_dualpath_fused_supported(C.byref(a)) else L.PATH_GENERIC
+        a.path = path
+    a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
+    LAST_PATH["dualpath_fwd"] = path
+    saved = _bytes(lib.mopk_dualpath_saved_bytes(C.byref(a)), dev)
+    ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
+    a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+    with _timed("dualpath_fwd"):
+        rc = lib.mopk_dualpath_fwd(C.byref(a), _stream())
+    L.check(rc, "mopk_dualpath_fwd")
+    return y, saved, path
+
+
+def _dp_bwd(ts, lg, y, saved, dy, gs, gates, beta_not, hops, m8, ms, causal, prec, path, drop):
+    """one mopk_dualpath_bwd call: gradients into the six (B,N,H,dk) views `gs`; -> d chain_logit partials (B,H)"""
+    lib = L.lib()
+    B, N, H, dk = ts[0].shape
+    dev = ts[0].device
+    a = L.DualPathArgs()
+    a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
+    a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, path, int(bool(causal))
+    a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
+    a.beta_not = float(beta_not)
+    a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
+    a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
+    a.chain_logit = lg.data_ptr()
+    a.y, a.dy = _v4(y), _v4(dy)
+    a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
+    a.dq1, a.dk1, a.dv1, a.dq2, a.dk2, a.dv2 = (_v4(g) for g in gs)
+    dlg = torch.empty(B, H, dtype=torch.float32, device=dev)
+    a.dlogit_part = dlg.data_ptr()
+    LAST_PATH["dualpath_bwd"] = path
+    ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
+    a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
+    with _timed("dualpath_bwd"):
+        rc = lib.mopk_dualpath_bwd(C.byref(a), _stream())
+    L.check(rc, "mopk_dualpath_bwd")
+    return dlg
+
+
 class _DualPathFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q1, k1, v1, q2, k2, v2, logit, gates, beta_not, hops, mask, causal, prec, path, drop=(0.0, 0)):
         _require_gpu(q1, "MultiHopMSA")
-        lib = L.lib()
+        ctx.packed = k1 is None            # packed form: q1 / q2 are the (B,N,3,H,dk) outputs of the two qkv projections (see _SdpaFn)
+        if ctx.packed:
+            q1, k1, v1 = q1.contiguous().unbind(2)
+            q2, k2, v2 = q2.contiguous().unbind(2)
         ts = [_heads_view(t) for t in (q1, k1, v1, q2, k2, v2)]
         B, N, H, dk = ts[0].shape
-        dev = ts[0].device
         lg = _f32c(logit).reshape(1)
-        a = L.DualPathArgs()
-        a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
-        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, path, int(bool(causal))
-        a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
-        a.beta_not = float(beta_not)
-        a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
-        m8, ms = _mask_u8(mask, B, H, N, dev)
-        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
-        a.chain_logit = lg.data_ptr()
-        y = torch.empty(B, N, H, dk, dtype=ts[0].dtype, device=dev)
-        a.y = _v4(y)
-        if path == L.PATH_AUTO:
-            path = L.PATH_FUSED if lib.mopk_dualpath_fused_supported(C.byref(a)) else L.PATH_GENERIC
-            a.path = path
-        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
-        LAST_PATH["dualpath_fwd"] = path
-        saved = _bytes(lib.mopk_dualpath_saved_bytes(C.byref(a)), dev)
-        ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
-        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
-        with _timed("dualpath_fwd"):
-            rc = lib.mopk_dualpath_fwd(C.byref(a), _stream())
-        L.check(rc, "mopk_dualpath_fwd")
+        m8, ms = _mask_u8(mask, B, H, N, ts[0].device)
+        y, saved, path = _dp_fwd(ts, lg, gates, beta_not, hops, m8, ms, causal, prec, path, drop)
         ctx.save_for_backward(*ts, lg, y, saved)
         ctx.meta = (gates, beta_not, hops, causal, prec, path, m8, ms, drop)
         return y.view(B, N, H * dk)
 
     @staticmethod
     def backward(ctx, dy):
-        lib = L.lib()
         *ts, lg, y, saved = ctx.saved_tensors
         gates, beta_not, hops, causal, prec, path, m8, ms, drop = ctx.meta
         B, N, H, dk = ts[0].shape
         dev = ts[0].device
         dy = dy.contiguous().to(ts[0].dtype).view(B, N, H, dk)
-        a = L.DualPathArgs()
-        a.B, a.H, a.N, a.dk, a.hops = B, H, N, dk, hops
-        a.io_dtype, a.precision, a.path, a.causal = _io_dtype(ts[0]), prec, path, int(bool(causal))
-        a.g_and, a.g_or, a.g_not, a.g_chain = (float(g) for g in gates)
-        a.beta_not = float(beta_not)
-        a.q1, a.k1, a.v1, a.q2, a.k2, a.v2 = (_v4(t) for t in ts)
-        a.mask, (a.mask_sb, a.mask_sh, a.mask_si) = _ptr(m8), ms
-        a.chain_logit = lg.data_ptr()
-        a.y, a.dy = _v4(y), _v4(dy)
-        a.dropout_p, a.dropout_seed = float(drop[0]), int(drop[1])
         mk = torch.zeros if hops == 0 else torch.empty          # hops == 0: dv2 is never written
-        gs = [mk(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(6)]
-        a.dq1, a.dk1, a.dv1, a.dq2, a.dk2, a.dv2 = (_v4(g) for g in gs)
-        dlg = torch.empty(B, H, dtype=torch.float32, device=dev)
-        a.dlogit_part = dlg.data_ptr()
-        ws = _bytes(lib.mopk_dualpath_workspace_bytes(C.byref(a)), dev)
-        a.saved, a.workspace = saved.data_ptr(), ws.data_ptr()
-        with _timed("dualpath_bwd"):
-            rc = lib.mopk_dualpath_bwd(C.byref(a), _stream())
-        L.check(rc, "mopk_dualpath_bwd")
+        if ctx.packed:
+            packs = [mk(B, N, 3, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(2)]
+            gs = [*packs[0].unbind(2), *packs[1].unbind(2)]
+        else:
+            gs = [mk(B, N, H, dk, dtype=ts[0].dtype, device=dev) for _ in range(6)]
+        dlg = _dp_bwd(ts, lg, y, saved, dy, gs, gates, beta_not, hops, m8, ms, causal, prec, path, drop)
+        if ctx.packed:
+            return (packs[0], None, None, packs[1], None, None, dlg.sum().reshape(()), None, None, None, None, None, None, None, None)
         return (*gs, dlg.sum().reshape(()), None, None, None, None, None, None, None, None)
+
+
+class _CrossViewFoldedFn(torch.autograd.Function):
+    """CrossViewMixerMSA without transpose cues / prior on the fused two-score kernels, from the PACKED projections:
+    S = q1 (m11 k1 + m12 k2)^T + q2 (m21 k1 + m22 k2)^T (reference :99-105): the 2x2 mix folds into two mixed key tensors built here
+    (no autograd graph), the core is the dual-path kernel pair without the transport term (hops = 0, v2 unused), and the backward
+    un-mixes dk1' / dk2' into dk1, dk2 and d mix and writes ONE gradient per projection."""
+
+    @staticmethod
+    def forward(ctx, qkv1, qkv2, mix, mask, causal, prec, drop):
+        _require_gpu(qkv1, "CrossViewMixerMSA")
+        q1, k1, v1 = qkv1.contiguous().unbind(2)
+        q2, k2, _ = qkv2.contiguous().unbind(2)
+        B, N, H, dk = q1.shape
+        m = mix.detach().to(k1.dtype)
+        k1p = (m[0, 0] * k1 + m[0, 1] * k2).contiguous()
+        k2p = (m[1, 0] * k1 + m[1, 1] * k2).contiguous()
+        ts = [q1, k1p, v1, q2, k2p, v1]
+        lg = torch.zeros(1, dtype=torch.float32, device=q1.device)
+        m8, ms = _mask_u8(mask, B, H, N, q1.device)
+        y, saved, path = _dp_fwd(ts, lg, (1.0, 0.0, 0.0, 0.0), 0.0, 0, m8, ms, causal, prec, L.PATH_FUSED, drop)
+        ctx.save_for_backward(qkv1, qkv2, mix, k1p, k2p, lg, y, saved)
+        ctx.meta = (causal, prec, path, m8, ms, drop)
+        return y.view(B, N, H * dk)
+
+    @staticmethod
+    def backward(ctx, dy):
+        qkv1, qkv2, mix, k1p, k2p, lg, y, saved = ctx.saved_tensors
+        causal, prec, path, m8, ms, drop = ctx.meta
+        q1, k1, v1 = qkv1.unbind(2)
+        q2, k2, _ = qkv2.unbind(2)
+        B, N, H, dk = q1.shape
+        dev = q1.device
+        dy = dy.contiguous().to(q1.dtype).view(B, N, H, dk)
+        d1, d2 = torch.empty_like(qkv1), torch.zeros_like(qkv2)            # v2 receives no gradient (:98)
+        dk1p, dk2p = torch.empty(B, N, H, dk, dtype=q1.dtype, device=dev), torch.empty(B, N, H, dk, dtype=q1.dtype, device=dev)
+        dv2 = torch.zeros(B, N, H, dk, dtype=q1.dtype, device=dev)          # hops == 0: never written
+        gs = [d1[:, :, 0], dk1p, d1[:, :, 2], d2[:, :, 0], dk2p, dv2]
+        _dp_bwd([q1, k1p, v1, q2, k2p, v1], lg, y, saved, dy, gs, (1.0, 0.0, 0.0, 0.0), 0.0, 0, m8, ms, causal, prec, path, drop)
+        m = mix.detach().to(q1.dtype)
+        d1k, d2k = d1[:, :, 1], d2[:, :, 1]                                  # k1' = m11 k1 + m12 k2, k2' = m21 k1 + m22 k2
+        torch.mul(dk1p, m[0, 0], out=d1k); d1k.addcmul_(dk2p, m[1, 0])
+        torch.mul(dk1p, m[0, 1], out=d2k); d2k.addcmul_(dk2p, m[1, 1])
+        f = lambda x, y_: (x.float() * y_.float()).sum()
+        dmix = torch.stack([torch.stack([f(dk1p, k1), f(dk1p, k2)]), torch.stack([f(dk2p, k1), f(dk2p, k2)])]).to(mix.dtype)
+        return d1, d2, dmix, None, None, None, None
 
 
 @_half_via_fp32
 def dualpath_core(q1, k1, v1, q2, k2, v2, chain_logit, g_and, g_or, g_not, g_chain, beta_not, hops,
                   attn_mask=None, causal=False, dropout_p: float = 0.0, seed: Optional[int] = None):
+    """q*, k*, v*: (B,N,H,dk) views -- or packed: q1 / q2 = the (B,N,3,H,dk) outputs of the two qkv projections, k1 = v1 = k2 = v2 = None"""
     if q1.shape[0] == 0:
-        return _empty_batch(q1, 0, q1.shape[1], q1.shape[2] * q1.shape[3])
+        return _empty_batch(q1, 0, q1.shape[1], q1.shape[-2] * q1.shape[-1])
     drop = (float(dropout_p), (dropout_seed() if seed is None else int(seed))) if dropout_p > 0 else (0.0, 0)
     return _DualPathFn.apply(q1, k1, v1, q2, k2, v2, chain_logit, (g_and, g_or, g_not, g_chain), beta_not,
                              int(hops), attn_mask, causal, _prec_for(q1.dtype), _PATH, drop)

@@ -8,7 +8,7 @@ from mop_amd.nn import (BaselineMSA, CausalSelfAttention, CrossViewMixerMSA, Mul
                         TransformerConfig)
 
 
-def timeit(fn, n=5, w=2):
+def timeit(fn, n=10, w=5):
     for _ in range(w):
         fn()
     torch.cuda.synchronize()
