@@ -71,6 +71,30 @@ def test_size_queries_need_no_gpu(lib):
     assert lib.mopk_edgewise_saved_bytes(C.byref(a)) == 0
 
 
+def test_lens_means_support_query_needs_no_gpu(lib):
+    """mopk_lens_means_supported: shape gating of the closed-form lens kernels (N <= 224, dk 16 / 32 / 64, L <= 4, L V <= 16, LDS budget)"""
+    from mop_amd import _lib
+    a = _lib.LensMeansArgs()
+    a.B, a.H, a.N, a.dk, a.V, a.L = 2, 6, 197, 64, 5, 2
+    a.dil[0], a.dil[1] = 1, 2
+    assert lib.mopk_lens_means_supported(C.byref(a), 0) == 1 and lib.mopk_lens_means_supported(C.byref(a), 1) == 1
+    a.N = 225
+    assert lib.mopk_lens_means_supported(C.byref(a), 0) == 0
+    a.N, a.dk = 197, 48
+    assert lib.mopk_lens_means_supported(C.byref(a), 0) == 0
+    a.dk, a.V, a.L = 64, 5, 4                      # L V = 20 channels
+    for i in range(4):
+        a.dil[i] = 1
+    assert lib.mopk_lens_means_supported(C.byref(a), 0) == 0
+    a.V, a.L, a.N = 4, 4, 224                      # 16 channels: the backward's working set grows with the largest dilation
+    assert lib.mopk_lens_means_supported(C.byref(a), 1) == 1
+    a.dil[3] = 200
+    assert lib.mopk_lens_means_supported(C.byref(a), 0) == 1 and lib.mopk_lens_means_supported(C.byref(a), 1) == 0
+    a.dil[3] = 0
+    assert lib.mopk_lens_means_supported(C.byref(a), 0) == 0
+    assert lib.mopk_lens_means_fwd(None, None) < 0 and lib.mopk_lens_means_bwd(None, None) < 0
+
+
 def test_bad_args_are_rejected_before_any_launch(lib):
     from mop_amd import _lib
     a = _lib.EdgewiseArgs()
