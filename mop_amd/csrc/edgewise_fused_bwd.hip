@@ -1095,9 +1095,23 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
             *(bf16x8 *)dst = tl;
             *(bf16x8 *)(dst + 16) = th;
         };
-#pragma nounroll
+        // the Smix slab of this row block is requested in one batch (tile by tile, each p_tile() exposed its own HBM round trip: 14.7 k
+        // of this phase's 66 k cycles); register pressure is low here, the tile loop is over
+        u32x4 smx[NT][2];
+        {
+            const u32x4 *ps = slot(S_SM);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                smx[t][0] = __builtin_nontemporal_load(&ps[(2 * t) * 64]);
+                smx[t][1] = __builtin_nontemporal_load(&ps[trim_idx(2 * t + 1) * 64]);
+                if (ctrim && t == NT - 1) smx[t][1] = u32x4{0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u};       // trimmed chunk: Smix = -inf (padding keys)
+            }
+        }
+#pragma unroll
         for (int t = 0; t < NT; ++t) {
-            f32x16 P = p_tile(t);
+            f32x16 P = unpack_tile_h(smx[t][0], smx[t][1]);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) P[g] = __expf(P[g] - mxrow) * invl;
             if (drop.thresh) {                 // dv0 sees the dropped probabilities
 #pragma unroll
                 for (int g = 0; g < 16; ++g) P[g] = fa_drop_keep(drop, rowh, 32 * t + tile_row(g, h)) ? P[g] * drop.inv_keep : 0.f;
@@ -1165,11 +1179,16 @@ __global__ void __launch_bounds__(NT * 64, NT <= 3 ? 2 : 1) ew_fused_bwd_kernel(
         }
         // dlogit_part = (1-w) sum dy * (w y_chain)
         float dl = 0.f;
-        if (qok) {
+        if (qok) {                                      // 16-byte reads: dy of this lane's 8-channel chunks (full precision for fp32 I/O), w * y_chain as float4 pairs
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s) {
+                float dv8[8];
+                ld8_as_f32(dv8, dyrow + 16 * s + 8 * h);
+                const float4 y0 = *(const float4 *)&ych[(size_t)qi * DK + 16 * s + 8 * h], y1 = *(const float4 *)&ych[(size_t)qi * DK + 16 * s + 8 * h + 4];
+                const float yv[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dl = fmaf(ld_as_f32(dyrow + 16 * s + 8 * h + j), ych[(size_t)qi * DK + 16 * s + 8 * h + j], dl);   // full-precision dy
+                for (int j = 0; j < 8; ++j) dl = fmaf(dv8[j], yv[j], dl);
+            }
         }
         dl = wave_sum(dl);
         if (lane == 0) misc[4 + w] = dl;

@@ -63,6 +63,26 @@ template <> __device__ __forceinline__ bf16x8 load8_bf16<float>(const float *p) 
     r[4] = f2bf(b.x); r[5] = f2bf(b.y); r[6] = f2bf(b.z); r[7] = f2bf(b.w);
     return r;
 }
+// eight consecutive elements as floats (16-byte aligned): one 16-byte read (bf16) / two (fp32), exact
+__device__ __forceinline__ void ld8_as_f32(float (&v)[8], const unsigned short *p) {
+    const bf16x8 x = *(const bf16x8 *)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f((unsigned short)x[e]);
+}
+__device__ __forceinline__ void ld8_as_f32(float (&v)[8], const float *p) {
+    const float4 a = *(const float4 *)p, b = *(const float4 *)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+// four consecutive elements as floats (8-byte aligned for bf16, 16-byte for fp32)
+__device__ __forceinline__ void ld4_as_f32(float (&v)[4], const unsigned short *p) {
+    const uint2 x = *(const uint2 *)p;
+    v[0] = __builtin_bit_cast(float, x.x << 16); v[1] = __builtin_bit_cast(float, x.x & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, x.y << 16); v[3] = __builtin_bit_cast(float, x.y & 0xffff0000u);
+}
+__device__ __forceinline__ void ld4_as_f32(float (&v)[4], const float *p) {
+    const float4 a = *(const float4 *)p;
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
 template <typename IOT> __device__ __forceinline__ void store4(IOT *p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<float>(float *p, float a, float b, float c, float d) {
     *(float4 *)p = make_float4(a, b, c, d);
